@@ -1,0 +1,37 @@
+# Top-level build: everything is built IN-TREE so the .so files travel with the gpurun snapshot.
+#   make            -> hip + host + oracle (+ oracle/_ref when /root/reference exists)
+#   make hip        -> vision-processor_amd/libvp_hip.so   (hand-written HIP kernels + C ABI, gfx950)
+#   make host       -> vision-processor_amd/libvp_host.so  (C++ host side: synthetic frames, geometry)
+#   make facade     -> vision-processor_amd/host/vp_frame_loop (C++ facade demo of main.cpp:262-317)
+PKG      := vision-processor_amd
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+# strict IEEE binary32: no contraction, no fast-math
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Wall -Wno-unused-function
+CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -Wall -pthread
+
+HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
+HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) include/vp_hip.h
+HOST_SRCS := $(PKG)/host/synth.cpp $(PKG)/host/geometry.cpp
+
+.PHONY: all hip host oracle facade clean
+all: hip host oracle facade
+
+hip: $(PKG)/libvp_hip.so
+$(PKG)/libvp_hip.so: $(HIP_SRCS) $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+
+host: $(PKG)/libvp_host.so
+$(PKG)/libvp_host.so: $(HOST_SRCS) include/vp_hip.h $(wildcard $(PKG)/host/*.h)
+	g++ $(CXXFLAGS) -shared -o $@ $(HOST_SRCS)
+
+facade: $(PKG)/host/vp_frame_loop
+$(PKG)/host/vp_frame_loop: $(PKG)/host/frame_loop.cpp $(wildcard $(PKG)/host/*.h) $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
+	g++ $(CXXFLAGS) -o $@ $(PKG)/host/frame_loop.cpp -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..'
+
+oracle:
+	$(MAKE) -s -C oracle oracle ref
+
+clean:
+	rm -f $(PKG)/libvp_hip.so $(PKG)/libvp_host.so $(PKG)/host/vp_frame_loop
+	$(MAKE) -s -C oracle clean

@@ -1,0 +1,194 @@
+/*
+ * vp_hip.h -- C ABI of the MI355X-native blob-detection hot path (libvp_hip.so).
+ *
+ * This is the drop-in boundary for the reference's per-frame GPU chain
+ *     raw2quad -> resampling -> gradientDot -> satHorizontal/satVertical -> satBlobCenter -> blobList
+ * (SURVEY.md section 8).  Every entry point cites the reference interface it replaces (file:line under the reference
+ * tree).  Signatures use only plain pointers, sizes and PODs; all image pointers are DEVICE pointers to tightly
+ * packed row-major data; `batch` frames are stored back to back.  All launches are asynchronous on the context's
+ * HIP stream `stream` (0 <= stream < n_streams); nothing here synchronises except vp_sync and the map helpers.
+ *
+ * Errors: every function returns VP_OK (0) or a negative VpStatus and stores a message retrievable with
+ * vp_last_error() (thread-local).  The C++ facade above this ABI turns any non-zero status into the reference's
+ * FATAL() behaviour (log.h:21: stderr + exit(1)).
+ *
+ * The library fails loudly when no HIP device is usable; there is no CPU fallback of any kind.
+ */
+#ifndef VP_HIP_H
+#define VP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	VP_OK = 0,
+	VP_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+	VP_ERR_HIP = -2,         /* a HIP runtime call failed (message holds hipGetErrorString) */
+	VP_ERR_NOMEM = -3,
+	VP_ERR_TIMEOUT = -4,     /* a bounded in-kernel wait expired (single-pass SAT look-back) */
+	VP_ERR_NODEVICE = -5
+} VpStatus;
+
+/* PixelFormat::RGGB8 / GRBG8 / BGR8 (opencl.h:41-45, opencl.cpp:29-31: the -DRGGB/-DGRBG/-DBGR kernel options) */
+typedef enum { VP_LAYOUT_RGGB = 0, VP_LAYOUT_GRBG = 1, VP_LAYOUT_BGR = 2 } VpLayout;
+
+/* Behaviour of read_imageui through CLK_FILTER_LINEAR on an integer image (resampling.cl:50), which OpenCL leaves
+ * undefined.  NEAREST: texel floor(u), clamp-to-edge.  BILINEAR_RTZ: spec 8.2 linear formula in binary32,
+ * truncated toward zero.  Recorded with every parity result. */
+typedef enum { VP_SAMPLER_NEAREST = 0, VP_SAMPLER_BILINEAR_RTZ = 1 } VpSamplerMode;
+
+/* Summed-area-table implementations.  All produce the same int32 (wrap-around) table; box sums taken from it are
+ * exact, and equal the reference's binary32 SAT whenever max|SAT| < 2^24.
+ *   TILED    : single pass, LDS-tiled local scans + decoupled look-back of tile carries (8 B/px HBM traffic)
+ *   TWOPASS  : global row pass then column pass ("global-recursive" comparison variant, 16 B/px) */
+typedef enum { VP_SAT_TILED = 0, VP_SAT_TWOPASS = 1 } VpSatVariant;
+
+/* Order of the blob list.  ATOMIC = append order of the device atomics, as in blobList.cl:87 (run-dependent);
+ * RASTER = records sorted by pixel index (deterministic whenever counter[0] <= max_matches). */
+typedef enum { VP_ORDER_ATOMIC = 0, VP_ORDER_RASTER = 1 } VpListOrder;
+
+/* CLCameraModel, Perspective.h:22-29 == resampling.cl:20-27.  72 bytes, packed, passed by value to the kernel.
+ * `f` is the focal length in quad-plane pixels (Perspective.cpp:140); shape is carried but unused (resampling.cl:29-47). */
+typedef struct __attribute__((packed)) {
+	int32_t shape[2];
+	float f;
+	float p[2];
+	float d;
+	float r[9]; /* row-major field->image rotation */
+	float c[3]; /* camera position, field coordinates */
+} VpCameraModel;
+
+/* CLMatch, main.cpp:33-41 == Match in blobList.cl:26-32.  22 bytes, packed (floats at offsets 0,4,14,18 are unaligned). */
+typedef struct __attribute__((packed)) {
+	float x, y;        /* sub-pixel flat coordinates */
+	uint8_t color[3];  /* mean dRGB over the disc */
+	uint8_t center[3]; /* dRGB at the peak pixel */
+	float circ;
+	float score;
+} VpMatch;
+
+typedef struct VpContext VpContext;
+
+/* ---- context / runtime: replaces OpenCL::OpenCL, wait, printRuntimes, clearEvents (opencl.h:72-112, opencl.cpp:34-101)
+ * vp_ctx_create picks HIP device `device`, creates n_streams in-order streams (the reference uses one in-order queue,
+ * opencl.cpp:48).  vp_ctx_adopt_stream wraps an existing hipStream_t (e.g. a PyTorch stream) as stream 0. */
+int vp_ctx_create(int device, int n_streams, VpContext** out);
+int vp_ctx_adopt_stream(int device, void* hip_stream, VpContext** out);
+void vp_ctx_destroy(VpContext* ctx);
+int vp_sync(VpContext* ctx, int stream);              /* OpenCL::wait (opencl.cpp:87-92); stream < 0 = all */
+const char* vp_last_error(void);
+int vp_device_count(void);
+const char* vp_device_name(VpContext* ctx);
+
+/* per-launch timing, the analogue of the stored cl::Event list (opencl.h:84, opencl.cpp:94-105).  When enabled every
+ * stage launch is bracketed by hipEvents; vp_event_times syncs the stream and returns up to `cap` {tag, ms} pairs. */
+typedef struct { const char* stage; float ms; } VpStageTime;
+int vp_events_enable(VpContext* ctx, int on);
+int vp_event_times(VpContext* ctx, VpStageTime* out, int cap);  /* printRuntimes */
+int vp_events_clear(VpContext* ctx);                            /* clearEvents   */
+
+/* ---- memory: replaces clAlloc / CLArray / CLImage allocation and the blocking map/unmap RAII (opencl.cpp:137-159,
+ * opencl.h:115-165,215-262).  Device memory is plain hipMalloc; host memory is pinned (the CL_MEM_ALLOC_HOST_PTR analogue).
+ * The copies are asynchronous on `stream`; the *_sync forms also wait, like a blocking clEnqueueMapBuffer. */
+int vp_malloc_device(VpContext* ctx, size_t bytes, void** dptr);
+int vp_free_device(VpContext* ctx, void* dptr);
+int vp_malloc_host(VpContext* ctx, size_t bytes, void** hptr);
+int vp_free_host(VpContext* ctx, void* hptr);
+int vp_copy_h2d(VpContext* ctx, int stream, void* dst_d, const void* src_h, size_t bytes);
+int vp_copy_d2h(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes);
+int vp_copy_d2h_sync(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes);
+int vp_memset_device(VpContext* ctx, int stream, void* dst_d, int value, size_t bytes);
+
+/* ---- stage kernels ------------------------------------------------------------------------------------------------ */
+
+/* raw2quad (raw2quad.cl:21-39; launched by Resources::raw2quad, Resources.cpp:138-143).
+ * raw: batch x (Bayer: 2qh x 2qw bytes | BGR: qh x qw x 3 bytes).  planes: batch x 4 x qh x qw (plane 3 untouched for BGR). */
+int vp_raw2quad(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int batch, uint8_t* planes);
+
+/* resampling + field2image (resampling.cl:29-100; Resources.cpp:159).  planes as written by vp_raw2quad.
+ * flat: batch x fh x fw RGBA8 (delta-RGB, alpha 255). */
+int vp_resample(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, const VpCameraModel* model,
+		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat);
+
+/* Fused raw2quad+resampling: same result as vp_raw2quad followed by vp_resample, reading the raw buffer directly
+ * (the planes are never materialised). */
+int vp_resample_raw(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const VpCameraModel* model,
+		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat);
+
+/* gradient_dotproduct (gradientDot.cl:22-30; Resources.cpp:160).  graddot: batch x h x w float (exact integers). */
+int vp_graddot(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, float* graddot);
+
+/* sat_horizontal + sat_vertical (satHorizontal.cl:22-32, satVertical.cl:22-32; Resources.cpp:161-162) on a gradDot image. */
+int vp_sat(VpContext* ctx, int stream, const float* graddot, int w, int h, int batch, int variant, int32_t* sat);
+
+/* Fused gradient_dotproduct + SAT: the pass BASELINE.json's HBM-roofline figure is quoted on (8 B/px algorithmic:
+ * read flat once, write SAT once).  graddot_out may be NULL; if not it also receives the F32 gradDot debug view. */
+int vp_graddot_sat(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, int variant,
+		int32_t* sat, float* graddot_out);
+
+/* circle (satBlobCenter.cl:34-42; Resources.cpp:163) on the int32 SAT.  blobcenter: batch x h x w float. */
+int vp_blobcenter(VpContext* ctx, int stream, const int32_t* sat, int w, int h, int radius, int batch, float* blobcenter);
+
+/* matches (blobList.cl:36-103; launched by main.cpp:289 with the counter protocol of main.cpp:283-288,299-316).
+ * matches: batch x max_matches records; idx: batch x max_matches pixel indices (y*w+x) parallel to matches (may be NULL);
+ * counter: batch x 3 ints {appended (may exceed max_matches), score-rejected, non-peak-rejected}; zeroed by this call. */
+int vp_bloblist(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch,
+		float circ_threshold, float min_score, int radius, int max_matches, int order,
+		VpMatch* matches, uint32_t* idx, int32_t* counter);
+
+/* Fused circle + matches straight from the SAT (blobCenter stays in LDS).  blobcenter_out may be NULL. */
+int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* flat, const int32_t* sat, int w, int h, int batch,
+		int circle_radius, float circ_threshold, float min_score, int list_radius, int max_matches, int order,
+		VpMatch* matches, uint32_t* idx, int32_t* counter, float* blobcenter_out);
+
+/* matches (blobScore.cl:23-67; compiled at blob_benchmark.cpp:117, launch commented out :154-155): score image. */
+int vp_blobscore(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch,
+		float circ_threshold, int radius, float* score);
+
+/* circularize (blobCenter.cl:29-63; never compiled by the reference): non-SAT quadrant ringness, for cross-checks. */
+int vp_circularize(VpContext* ctx, int stream, const float* graddot, int w, int h, int batch, int min_radius, int max_radius, float* out);
+
+/* ---- whole frame: Resources::raw2quad + Resources::rgba2blobCenter + the blobList launch of main.cpp:283-289 ---------- */
+typedef struct {
+	int32_t layout, qw, qh;            /* RawImage format/width/height (opencl.h:168-188; Bayer: 2x2-cell counts) */
+	VpCameraModel model;               /* Perspective::getCLCameraModel (Perspective.cpp:136-150) */
+	float max_robot_height;            /* gcSocket->maxBotHeight (Resources.cpp:159) */
+	float field_scale, off_x, off_y;   /* perspective->fieldScale, visibleFieldExtent[0], visibleFieldExtent[2] */
+	int32_t fw, fh;                    /* perspective->reprojectedFieldSize */
+	int32_t grad_offset;               /* (int)ceilf(maxBlobRadius/fieldScale)/3   (Resources.cpp:160) */
+	int32_t circle_radius;             /* (int)ceilf(minBlobRadius/fieldScale)     (Resources.cpp:163) */
+	int32_t list_radius;               /* (int)floorf(minBlobRadius/fieldScale)    (main.cpp:289) */
+	float circ_threshold;              /* (float)minCircularity                    (main.cpp:289) */
+	float min_score;                   /* 0.0f at the reference call site          (main.cpp:289) */
+	int32_t max_matches;               /* maxBlobs */
+	int32_t sampler_mode, sat_variant, order;
+} VpFrameParams;
+
+typedef struct {
+	uint8_t* flat;        /* required: batch x fh x fw x 4 */
+	int32_t* sat;         /* required: batch x fh x fw */
+	VpMatch* matches;     /* required: batch x max_matches */
+	uint32_t* idx;        /* optional */
+	int32_t* counter;     /* required: batch x 3 */
+	uint8_t* planes;      /* optional debug/stream view: batch x 4 x qh x qw (Resources::raw2quad output) */
+	float* graddot;       /* optional debug view (main.cpp:291-295, 377-394) */
+	float* blobcenter;    /* optional debug view / blob_benchmark input (blob_benchmark.cpp:162) */
+} VpFrameBuffers;
+
+/* raw -> blob list for `batch` frames on one stream, no host synchronisation inside. */
+int vp_frame(VpContext* ctx, int stream, const VpFrameParams* params, const uint8_t* raw, int batch, const VpFrameBuffers* buffers);
+
+/* ---- synthetic input (libvp_host.so; host-side, no GPU) --------------------------------------------------------------
+ * Deterministic test/benchmark frames; not part of the reference. */
+int vp_synth_frame(const VpCameraModel* model, int layout, int qw, int qh, float plane_height, float field_len, float field_wid,
+		uint32_t seed, int n_robots, int n_balls, float noise_sigma, uint8_t* raw);
+void vp_synth_camera(int qw, int qh, float cam_height, float plane_height, float visible_len, float distortion, VpCameraModel* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_HIP_H */
