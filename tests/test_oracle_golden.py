@@ -1,0 +1,86 @@
+"""The CPU restatement (oracle/vp_oracle.c) against the committed golden vectors, stage by stage.
+
+The vectors were produced by the reference's own kernels compiled for x86 (tests/golden/make_golden.py); this test
+runs everywhere (no /root/reference, no GPU needed)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+
+def _matches(buf):
+    return np.frombuffer(buf.tobytes(), O.MATCH_DTYPE)
+
+
+@pytest.mark.parametrize("cfg,mode,seed", cases.CHAIN_CASES, ids=[cases.chain_case_name(*c) for c in cases.CHAIN_CASES])
+def test_chain_stages_bit_exact(port, cfg, mode, seed):
+    g = cases.load_golden(cases.chain_case_name(cfg, mode, seed))
+    assert np.array_equal(cfg.synth(seed), g["raw"]), "synthetic frame generator drifted from the fixture"
+    model = O.CameraModel.from_array(g["model"])
+    mrh, fs, ox, oy, thr, min_score = [float(v) for v in g["scalars"]]
+    o, r, R, max_matches, smode = [int(v) for v in g["ints"]]
+    assert (o, r, R, smode) == (cfg.grad_offset, cfg.circle_radius, cfg.list_radius, mode)
+
+    planes = port.raw2quad(g["raw"], int(g["layout"]), int(g["qw"]), int(g["qh"]))
+    n_planes = 3 if cfg.layout == cases.cfgs.BGR else 4
+    assert np.array_equal(planes[:n_planes], g["planes"][:n_planes])
+    flat = port.resample(g["planes"], int(g["layout"]), model, mrh, fs, ox, oy, smode, int(g["fw"]), int(g["fh"]))
+    assert np.array_equal(flat, g["flat"])
+    gd = port.graddot(g["flat"], o)
+    assert np.array_equal(gd, g["graddot"].astype(np.float32))
+    sat = port.sat(gd)
+    assert np.array_equal(sat, g["sat"].astype(np.float32))
+    sat_i, max_abs = port.sat_i32(gd)
+    assert max_abs == int(g["max_abs_sat"]) < 2 ** 24
+    assert np.array_equal(sat_i, g["sat"])  # int32 table == binary32 table under the guard (H2)
+    bc = port.blobcenter(sat, r)
+    assert np.array_equal(bc, g["blobcenter"])
+    assert np.array_equal(port.blobcenter_i32(sat_i, r), g["blobcenter"])
+    m, idx, cnt = port.bloblist(g["flat"], g["blobcenter"], thr, min_score, R, max_matches)
+    assert np.array_equal(cnt, g["counter"])
+    assert np.array_equal(idx, g["idx"])
+    assert m.tobytes() == g["matches"].tobytes()
+    if "blobscore" in g:
+        assert np.array_equal(port.blobscore(g["flat"], g["blobcenter"], thr, R), g["blobscore"])
+        assert np.array_equal(port.circularize(gd, R, r), g["circularize"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", sorted(cases.flat_cases()))
+def test_flat_edge_cases_bit_exact(port, name):
+    g = cases.load_golden(name)
+    c = cases.flat_cases()[name]
+    assert np.array_equal(c["flat"], g["flat"])
+    o, r, R, max_matches = [int(v) for v in g["ints"]]
+    thr, min_score = [float(v) for v in g["scalars"]]
+    gd = port.graddot(g["flat"], o)
+    assert np.array_equal(gd, g["graddot"].astype(np.float32))
+    sat = port.sat(gd)
+    sat_i, max_abs = port.sat_i32(gd)
+    if "sat" in g:
+        assert np.array_equal(sat, g["sat"].astype(np.float32)) and np.array_equal(sat_i, g["sat"])
+    else:  # guard violated: the fp32 path must still reproduce the reference's rounding; the int path is the exact table
+        assert max_abs >= 2 ** 24
+        assert np.array_equal(sat, g["sat_f32"])
+        assert not np.array_equal(sat_i.astype(np.float32), g["sat_f32"])
+    bc = port.blobcenter(sat, r)
+    assert np.array_equal(bc, g["blobcenter"])
+    m, idx, cnt = port.bloblist(g["flat"], g["blobcenter"], thr, min_score, R, max_matches)
+    assert np.array_equal(cnt, g["counter"]) and np.array_equal(idx, g["idx"])
+    assert m.tobytes() == g["matches"].tobytes()
+    gm = _matches(g["matches"])
+    assert len(gm) == min(int(cnt[0]), max_matches)
+
+
+def test_edge_cases_do_what_they_claim():
+    g = cases.load_golden("flat_uniform_discs")
+    m = _matches(g["matches"])
+    assert np.isinf(m["score"]).any() and np.isnan(m["x"]).any()       # H5
+    g = cases.load_golden("flat_constant_overflow")
+    assert g["counter"][0] == 24 * 32 > g["ints"][3]                    # every pixel appended, list overflows
+    assert np.isnan(_matches(g["matches"])["score"]).all()
+    g = cases.load_golden("flat_overflow_minscore")
+    assert g["counter"][0] > g["ints"][3] and g["counter"][1] > 0
+    g = cases.load_golden("flat_offset0")
+    assert not g["graddot"].any() and g["counter"][0] == 0
+    assert "sat_f32" in cases.load_golden("flat_guard_violation")

@@ -1,0 +1,59 @@
+"""The CPU restatement against the reference's own compiled kernels (oracle/_ref), live, on inputs beyond the fixtures.
+Skipped where oracle/_ref was never built (it needs /root/reference at build time; the built .so travels to the GPU box)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+cfgs = cases.cfgs
+
+
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.T_RAGGED.with_(layout=cfgs.GRBG), cfgs.T_BGR.with_(distortion=-0.12)], ids=lambda c: c.name)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_chain_port_equals_reference(port, ref, cfg, mode):
+    raw = cfg.synth(7)
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    res = {}
+    for impl in (port, ref):
+        planes = impl.raw2quad(raw, cfg.layout, cfg.qw, cfg.qh)
+        flat = impl.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, mode, cfg.fw, cfg.fh)
+        ch = impl.chain_from_flat(flat, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, cfg.max_matches)
+        ch.update(planes=planes[: 3 if cfg.layout == cfgs.BGR else 4], flat=flat)
+        res[impl.name] = ch
+    a, b = res["port"], res["reference"]
+    for k in ("planes", "flat", "graddot", "sat", "blobcenter", "idx", "counter"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["matches"].tobytes() == b["matches"].tobytes()
+    assert len(a["matches"]) > 0
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_flat_port_equals_reference(port, ref, seed):
+    rng = np.random.default_rng(seed)
+    h, w = int(rng.integers(20, 90)), int(rng.integers(20, 120))
+    flat = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    flat[..., 3] = 255
+    o, r, R = int(rng.integers(0, 4)), int(rng.integers(2, 8)), int(rng.integers(1, 6))
+    thr = float(rng.choice([-1e9, 0.0, 15.0, 500.0]))
+    a = port.chain_from_flat(flat, o, r, R, thr, 0.0, 300)
+    b = ref.chain_from_flat(flat, o, r, R, thr, 0.0, 300)
+    for k in ("graddot", "sat", "blobcenter", "idx", "counter"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert a["matches"].tobytes() == b["matches"].tobytes()
+    assert np.array_equal(port.blobscore(flat, a["blobcenter"], thr, R), ref.blobscore(flat, b["blobcenter"], thr, R), equal_nan=True)
+    assert np.array_equal(port.circularize(a["graddot"], R, r), ref.circularize(b["graddot"], R, r), equal_nan=True)
+
+
+def test_threads_do_not_change_results(port):
+    cfg = cfgs.T_MID
+    raw = cfg.synth(3)
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    one = O.Port(threads=1)
+    args = (raw, cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh,
+            cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold)
+    m1, i1, c1 = one.frame(*args)
+    m4, i4, c4 = port.frame(*args)
+    assert m1.tobytes() == m4.tobytes() and np.array_equal(i1, i4) and np.array_equal(c1, c4)
+    m5, i5, c5 = port.frame(*args, sat_mode=1)  # int32 SAT path gives the same list under the guard
+    assert m1.tobytes() == m5.tobytes() and np.array_equal(c1, c5)
