@@ -25,7 +25,11 @@ host: $(PKG)/libvp_host.so
 $(PKG)/libvp_host.so: $(HOST_SRCS) include/vp_hip.h $(wildcard $(PKG)/host/*.h)
 	g++ $(CXXFLAGS) -shared -o $@ $(HOST_SRCS)
 
+ifneq ($(wildcard $(PKG)/host/frame_loop.cpp),)
 facade: $(PKG)/host/vp_frame_loop
+else
+facade:
+endif
 $(PKG)/host/vp_frame_loop: $(PKG)/host/frame_loop.cpp $(wildcard $(PKG)/host/*.h) $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
 	g++ $(CXXFLAGS) -o $@ $(PKG)/host/frame_loop.cpp -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..'
 

@@ -1,0 +1,285 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libvp_hip.so), against
+  (a) the committed golden vectors (generated from the reference's own kernels),
+  (b) the CPU oracle on the same seeded inputs at sizes it finishes in seconds,
+  (c) size-independent properties at BASELINE.json's full 2048x1536 size.
+Bar: integer / byte / index outputs bit-exact; float circularity / centroid / score within 1e-4 (abs-or-rel, NaN==NaN,
+inf==inf) -- in practice they are bit-exact too and the tests say so where they check it."""
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi = cases.vp.load_capi()
+    ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    yield capi, ctx, torch
+    ctx.close()
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+import os
+
+VARIANTS = [("twopass", 1), ("tiled", 0)]
+if os.environ.get("VP_TEST_SAT"):  # e.g. VP_TEST_SAT=twopass while bisecting a variant
+    VARIANTS = [v for v in VARIANTS if v[0] in os.environ["VP_TEST_SAT"].split(",")]
+DEFAULT_VARIANT = VARIANTS[-1][1]
+
+
+def run_tail(capi, ctx, torch, flat, bc, w, h, thr, min_score, R, max_matches, order):
+    d_m = torch.zeros(max_matches * 22, dtype=torch.uint8, device="cuda")
+    d_idx = torch.zeros(max_matches, dtype=torch.int32, device="cuda")
+    d_cnt = torch.full((3,), -7, dtype=torch.int32, device="cuda")
+    ctx.bloblist(flat, bc, w, h, 1, thr, min_score, R, max_matches, order, d_m, d_idx, d_cnt)
+    ctx.sync()
+    return host(d_m), host(d_idx).view(np.uint32), host(d_cnt)
+
+
+def assert_list_equal(capi, got, want_matches_bytes, want_idx, want_cnt, max_matches, overflow_ok=False):
+    m_b, idx, cnt = got
+    assert np.array_equal(cnt, want_cnt), (cnt, want_cnt)
+    gm, gi = capi.sorted_blobs(m_b, idx, cnt, max_matches)
+    wm = np.frombuffer(np.ascontiguousarray(want_matches_bytes).tobytes(), capi.MATCH_DTYPE)
+    if int(cnt[0]) > max_matches:
+        # list overflow: which records survive is run-dependent in the reference too (blobList.cl:87-89); every survivor must be genuine
+        assert overflow_ok and len(gm) == max_matches and len(np.unique(gi)) == max_matches
+        return
+    assert np.array_equal(gi, want_idx)
+    assert np.array_equal(gm["color"], wm["color"]) and np.array_equal(gm["center"], wm["center"])
+    for k in ("x", "y", "circ", "score"):
+        assert np.allclose(gm[k], wm[k], rtol=1e-4, atol=1e-4, equal_nan=True), k
+    assert gm.tobytes() == wm.tobytes(), "floats are expected to be bit-exact as well"
+
+
+@pytest.mark.parametrize("cfg,mode,seed", cases.CHAIN_CASES, ids=[cases.chain_case_name(*c) for c in cases.CHAIN_CASES])
+def test_golden_chain_stage_by_stage(gpu, cfg, mode, seed):
+    capi, ctx, torch = gpu
+    g = cases.load_golden(cases.chain_case_name(cfg, mode, seed))
+    model = cases.vp.hostlib.VpCameraModel.from_buffer_copy(g["model"].tobytes())
+    mrh, fs, ox, oy, thr, min_score = [float(v) for v in g["scalars"]]
+    o, r, R, max_matches, smode = [int(v) for v in g["ints"]]
+    qw, qh, fw, fh, layout = int(g["qw"]), int(g["qh"]), int(g["fw"]), int(g["fh"]), int(g["layout"])
+    n_planes = 3 if layout == cfgs.BGR else 4
+
+    d_raw = dev(torch, g["raw"])
+    d_planes = torch.zeros((4, qh, qw), dtype=torch.uint8, device="cuda")
+    ctx.raw2quad(d_raw, layout, qw, qh, 1, d_planes)
+    assert np.array_equal(host(d_planes)[:n_planes], g["planes"][:n_planes])
+
+    d_flat = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+    ctx.resample(dev(torch, g["planes"]), layout, qw, qh, model, mrh, fs, ox, oy, smode, fw, fh, 1, d_flat)
+    assert np.array_equal(host(d_flat), g["flat"])
+    d_flat2 = torch.zeros_like(d_flat)
+    ctx.resample_raw(d_raw, layout, qw, qh, model, mrh, fs, ox, oy, smode, fw, fh, 1, d_flat2)
+    assert np.array_equal(host(d_flat2), g["flat"]), "fused raw2quad+resampling"
+
+    d_flat = dev(torch, g["flat"])
+    d_gd = torch.zeros((fh, fw), dtype=torch.float32, device="cuda")
+    ctx.graddot(d_flat, fw, fh, o, 1, d_gd)
+    assert np.array_equal(host(d_gd), g["graddot"].astype(np.float32))
+
+    for name, variant in VARIANTS:
+        d_sat = torch.zeros((fh, fw), dtype=torch.int32, device="cuda")
+        ctx.sat(d_gd, fw, fh, 1, variant, d_sat)
+        assert np.array_equal(host(d_sat), g["sat"]), f"sat {name}"
+        d_sat2 = torch.zeros_like(d_sat)
+        d_gd2 = torch.zeros_like(d_gd)
+        ctx.graddot_sat(d_flat, fw, fh, o, 1, variant, d_sat2, d_gd2)
+        assert np.array_equal(host(d_sat2), g["sat"]), f"fused graddot+sat {name}"
+        assert np.array_equal(host(d_gd2), g["graddot"].astype(np.float32))
+
+    d_sat = dev(torch, g["sat"])
+    d_bc = torch.zeros((fh, fw), dtype=torch.float32, device="cuda")
+    ctx.blobcenter(d_sat, fw, fh, r, 1, d_bc)
+    assert np.array_equal(host(d_bc), g["blobcenter"])
+
+    d_bc = dev(torch, g["blobcenter"])
+    for order in (capi.ORDER_ATOMIC, capi.ORDER_RASTER):
+        got = run_tail(capi, ctx, torch, d_flat, d_bc, fw, fh, thr, min_score, R, max_matches, order)
+        assert_list_equal(capi, got, g["matches"], g["idx"], g["counter"], max_matches)
+        if order == capi.ORDER_RASTER:  # RASTER is already sorted: byte-identical to the golden list
+            n = int(got[2][0])
+            assert got[0][: 22 * n].tobytes() == g["matches"].tobytes() and np.array_equal(got[1][:n], g["idx"])
+
+    if "blobscore" in g:
+        d_s = torch.zeros((fh, fw), dtype=torch.float32, device="cuda")
+        ctx.blobscore(d_flat, d_bc, fw, fh, 1, thr, R, d_s)
+        assert np.array_equal(host(d_s), g["blobscore"])
+        ctx.circularize(d_gd, fw, fh, 1, R, r, d_s)
+        assert np.array_equal(host(d_s), g["circularize"], equal_nan=True)
+
+
+@pytest.mark.parametrize("cfg,mode,seed", cases.CHAIN_CASES, ids=[cases.chain_case_name(*c) for c in cases.CHAIN_CASES])
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: v[0])
+def test_golden_whole_frame(gpu, cfg, mode, seed, variant):
+    capi, ctx, torch = gpu
+    g = cases.load_golden(cases.chain_case_name(cfg, mode, seed))
+    p = capi.frame_params(cfg, sat_variant=variant[1], order=capi.ORDER_RASTER, sampler_mode=mode)
+    mm = cfg.max_matches
+    d = dict(flat=torch.zeros((cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+             matches=torch.zeros(mm * 22, dtype=torch.uint8, device="cuda"), idx=torch.zeros(mm, dtype=torch.int32, device="cuda"),
+             counter=torch.zeros(3, dtype=torch.int32, device="cuda"))
+    # hot path: nothing optional materialised
+    ctx.frame(p, dev(torch, g["raw"]), 1, **d)
+    ctx.sync()
+    assert np.array_equal(host(d["flat"]), g["flat"]) and np.array_equal(host(d["sat"]), g["sat"])
+    assert_list_equal(capi, (host(d["matches"]), host(d["idx"]).view(np.uint32), host(d["counter"])), g["matches"], g["idx"], g["counter"], mm)
+    # with every debug view requested (the Resources::rgba2blobCenter contract returns flat, gradDot, blobCenter)
+    views = dict(planes=torch.zeros((4, cfg.qh, cfg.qw), dtype=torch.uint8, device="cuda"), graddot=torch.zeros((cfg.fh, cfg.fw), dtype=torch.float32, device="cuda"),
+                 blobcenter=torch.zeros((cfg.fh, cfg.fw), dtype=torch.float32, device="cuda"))
+    ctx.frame(p, dev(torch, g["raw"]), 1, **d, **views)
+    ctx.sync()
+    n_planes = 3 if cfg.layout == cfgs.BGR else 4
+    assert np.array_equal(host(views["planes"])[:n_planes], g["planes"][:n_planes])
+    assert np.array_equal(host(views["graddot"]), g["graddot"].astype(np.float32))
+    assert np.array_equal(host(views["blobcenter"]), g["blobcenter"])
+    assert_list_equal(capi, (host(d["matches"]), host(d["idx"]).view(np.uint32), host(d["counter"])), g["matches"], g["idx"], g["counter"], mm)
+
+
+@pytest.mark.parametrize("name", sorted(cases.flat_cases()))
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: v[0])
+def test_golden_flat_edge_cases(gpu, name, variant):
+    capi, ctx, torch = gpu
+    g = cases.load_golden(name)
+    o, r, R, max_matches = [int(v) for v in g["ints"]]
+    thr, min_score = [float(v) for v in g["scalars"]]
+    h, w = g["flat"].shape[:2]
+    d_flat = dev(torch, g["flat"])
+    d_sat = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    d_gd = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    ctx.graddot_sat(d_flat, w, h, o, 1, variant[1], d_sat, d_gd)
+    assert np.array_equal(host(d_gd), g["graddot"].astype(np.float32))
+    exact_sat, _ = O.Port().sat_i32(g["graddot"].astype(np.float32))
+    assert np.array_equal(host(d_sat), exact_sat), "int32 wrap-around table"
+    d_bc = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+    ctx.blobcenter(d_sat, w, h, r, 1, d_bc)
+    if "sat" in g:
+        assert np.array_equal(host(d_sat), g["sat"])
+        assert np.array_equal(host(d_bc), g["blobcenter"])
+    else:
+        # 2^24 guard violated (H2): the reference's own binary32 table has lost integers; the exact table may differ from it
+        # by the reference's rounding error only.  Documented tolerance: |delta blobCenter| <= 16 * ulp(max|SAT|) / r^2.
+        tol = 16 * np.spacing(np.float32(g["max_abs_sat"])) / (r * r)
+        assert np.abs(host(d_bc) - g["blobcenter"]).max() <= tol
+        assert np.array_equal(host(d_bc), O.Port().blobcenter_i32(exact_sat, r))
+    # the list stage consumes blobCenter as given: unconditional parity
+    d_bc = dev(torch, g["blobcenter"])
+    for order in (capi.ORDER_ATOMIC, capi.ORDER_RASTER):
+        got = run_tail(capi, ctx, torch, d_flat, d_bc, w, h, thr, min_score, R, max_matches, order)
+        assert_list_equal(capi, got, g["matches"], g["idx"], g["counter"], max_matches, overflow_ok=True)
+
+
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.CFG1], ids=lambda c: c.name)
+def test_live_oracle_mid_sizes(gpu, port, cfg):
+    """Seeded inputs not in the fixtures, checked against the CPU oracle run in the same process."""
+    capi, ctx, torch = gpu
+    model_o = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    B = 3
+    raws = [cfg.synth(100 + i) for i in range(B)]
+    p = capi.frame_params(cfg, sat_variant=DEFAULT_VARIANT, order=capi.ORDER_RASTER)
+    mm = cfg.max_matches
+    d_raw = dev(torch, np.stack(raws))
+    d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+             matches=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"),
+             counter=torch.zeros((B, 3), dtype=torch.int32, device="cuda"))
+    ctx.frame(p, d_raw, B, **d)
+    ctx.sync()
+    for i in range(B):
+        m, idx, cnt = port.frame(raws[i], cfg.layout, cfg.qw, cfg.qh, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                 cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+        assert len(m) > 5
+        assert_list_equal(capi, (host(d["matches"][i]), host(d["idx"][i]).view(np.uint32), host(d["counter"][i])), np.frombuffer(m.tobytes(), np.uint8), idx, cnt, mm)
+
+
+def test_full_size_properties(gpu, port):
+    """BASELINE.json configs[1] (2048x1536): properties that do not need a full CPU reference run per frame."""
+    capi, ctx, torch = gpu
+    cfg = cfgs.CFG2
+    B = 2
+    raws = [cfg.synth(i) for i in range(B)]
+    d_raw = dev(torch, np.stack(raws))
+    mm = cfg.max_matches
+    out = {}
+    for name, variant in VARIANTS:
+        for order in (capi.ORDER_ATOMIC, capi.ORDER_RASTER):
+            p = capi.frame_params(cfg, sat_variant=variant, order=order)
+            d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+                     matches=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"),
+                     counter=torch.zeros((B, 3), dtype=torch.int32, device="cuda"), graddot=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.float32, device="cuda"))
+            ctx.frame(p, d_raw, B, **d)
+            ctx.sync()
+            out[(name, order)] = {k: host(v) for k, v in d.items()}
+    ref = out[(VARIANTS[0][0], capi.ORDER_RASTER)]
+    # both SAT variants and both list orders agree on every integer output and on the blob set
+    for key, o in out.items():
+        assert np.array_equal(o["flat"], ref["flat"]) and np.array_equal(o["sat"], ref["sat"]) and np.array_equal(o["counter"], ref["counter"]), key
+        for i in range(B):
+            a = capi.sorted_blobs(o["matches"][i], o["idx"][i].view(np.uint32), o["counter"][i], mm)
+            b = capi.sorted_blobs(ref["matches"][i], ref["idx"][i].view(np.uint32), ref["counter"][i], mm)
+            assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]), key
+    # SAT == 2-D cumulative sum of gradDot in int64 arithmetic (mod 2^32); exactness guard of the benchmark inputs
+    for i in range(B):
+        gd = ref["graddot"][i].astype(np.int64)
+        full = gd.cumsum(0).cumsum(1)
+        assert np.abs(full).max() < 2 ** 24, "benchmark inputs must satisfy the 2^24 guard (SURVEY H2)"
+        assert np.array_equal(ref["sat"][i], full.astype(np.int32))
+    # frame 0 against the CPU oracle end to end (a few seconds)
+    model_o = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    big = O.Port(threads=8)
+    m, idx, cnt = big.frame(raws[0], cfg.layout, cfg.qw, cfg.qh, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                            cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+    assert 50 < len(m) <= mm
+    assert_list_equal(capi, (ref["matches"][0], ref["idx"][0].view(np.uint32), ref["counter"][0]), np.frombuffer(m.tobytes(), np.uint8), idx, cnt, mm)
+    # the rendered robots are found: 16 robots x 5 blobs + 8 balls, each within 1.5 px of a detected blob of high circularity
+    gm, _ = capi.sorted_blobs(ref["matches"][0], ref["idx"][0].view(np.uint32), ref["counter"][0], mm)
+    strong = gm[gm["circ"] > 500]
+    assert 60 <= len(strong) <= 200
+
+
+def test_abi_memory_and_events(gpu):
+    """The plain-pointer half of the ABI (no torch): vp_malloc / copies / memset / stage timers."""
+    capi, _, torch = gpu
+    ctx = capi.Context(0, n_streams=2)
+    try:
+        assert "gfx950" in ctx.device_name
+        g = cases.load_golden("flat_borders")
+        h, w = g["flat"].shape[:2]
+        o, r, R, mm = [int(v) for v in g["ints"]]
+        d_flat, d_sat, d_bc = ctx.malloc(w * h * 4), ctx.malloc(w * h * 4), ctx.malloc(w * h * 4)
+        d_m, d_idx, d_cnt = ctx.malloc(mm * 22), ctx.malloc(mm * 4), ctx.malloc(12)
+        ctx.h2d(d_flat, g["flat"], stream=1)
+        ctx.events_enable(True)
+        ctx.graddot_sat(d_flat, w, h, o, 1, capi.SAT_TWOPASS, d_sat, None, stream=1)
+        ctx.blobcenter_list(d_flat, d_sat, w, h, 1, r, float(g["scalars"][0]), float(g["scalars"][1]), R, mm, capi.ORDER_RASTER, d_m, d_idx, d_cnt, d_bc, stream=1)
+        times = ctx.event_times()
+        assert [t[0] for t in times] == ["gradientDot+sat", "satBlobCenter+blobList"] and all(t[1] > 0 for t in times)
+        ctx.events_clear()
+        assert ctx.event_times() == []
+        assert np.array_equal(ctx.d2h(d_sat, (h, w), np.int32, stream=1), g["sat"])
+        assert np.array_equal(ctx.d2h(d_bc, (h, w), np.float32, stream=1), g["blobcenter"])
+        cnt = ctx.d2h(d_cnt, (3,), np.int32, stream=1)
+        assert np.array_equal(cnt, g["counter"])
+        n = int(cnt[0])
+        assert ctx.d2h(d_m, (n * 22,), np.uint8, stream=1).tobytes() == g["matches"].tobytes()
+        ctx.memset(d_cnt, 0, 12, stream=1)
+        assert not ctx.d2h(d_cnt, (3,), np.int32, stream=1).any()
+        with pytest.raises(capi.VpError):
+            ctx.graddot_sat(d_flat, w, h, o, 1, 99, d_sat, None)
+        for p in (d_flat, d_sat, d_bc, d_m, d_idx, d_cnt):
+            ctx.free(p)
+    finally:
+        ctx.close()

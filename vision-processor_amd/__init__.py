@@ -7,7 +7,7 @@ parameter sets.  The product is the HIP library and the C++ facade under host/.
 from . import configs, hostlib  # noqa: F401
 
 
-def capi():
+def load_capi():
     """Lazy import: loading libvp_hip.so requires the HIP runtime."""
     from . import capi as _capi
     return _capi

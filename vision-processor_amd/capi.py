@@ -1,0 +1,216 @@
+"""ctypes binding of libvp_hip.so (include/vp_hip.h).  Plumbing for tests and bench.py only.
+
+Device memory can be anything that yields a raw device pointer: `torch` CUDA(ROCm) tensors (`.data_ptr()`) or
+`Context.malloc`.  No compute ever happens in Python and there is no fallback: a missing library or device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .hostlib import VpCameraModel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(HERE, "libvp_hip.so")
+
+VP_OK = 0
+SAT_TILED, SAT_TWOPASS = 0, 1
+ORDER_ATOMIC, ORDER_RASTER = 0, 1
+
+MATCH_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("color", "u1", (3,)), ("center", "u1", (3,)), ("circ", "<f4"), ("score", "<f4")])
+assert MATCH_DTYPE.itemsize == 22
+
+
+class VpFrameParams(C.Structure):
+    _fields_ = [
+        ("layout", C.c_int32), ("qw", C.c_int32), ("qh", C.c_int32), ("model", VpCameraModel),
+        ("max_robot_height", C.c_float), ("field_scale", C.c_float), ("off_x", C.c_float), ("off_y", C.c_float),
+        ("fw", C.c_int32), ("fh", C.c_int32), ("grad_offset", C.c_int32), ("circle_radius", C.c_int32), ("list_radius", C.c_int32),
+        ("circ_threshold", C.c_float), ("min_score", C.c_float), ("max_matches", C.c_int32),
+        ("sampler_mode", C.c_int32), ("sat_variant", C.c_int32), ("order", C.c_int32),
+    ]
+
+
+class VpFrameBuffers(C.Structure):
+    _fields_ = [("flat", C.c_void_p), ("sat", C.c_void_p), ("matches", C.c_void_p), ("idx", C.c_void_p), ("counter", C.c_void_p),
+                ("planes", C.c_void_p), ("graddot", C.c_void_p), ("blobcenter", C.c_void_p)]
+
+
+class VpStageTime(C.Structure):
+    _fields_ = [("stage", C.c_char_p), ("ms", C.c_float)]
+
+
+class VpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vp_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_SO):
+            raise FileNotFoundError(f"{HIP_SO} missing: the HIP extension is required (run `make hip` / __graft_entry__.build()); there is no fallback")
+        _lib = C.CDLL(HIP_SO)
+        _lib.vp_last_error.restype = C.c_char_p
+        _lib.vp_device_name.restype = C.c_char_p
+        _lib.vp_device_name.argtypes = [C.c_void_p]
+        _lib.vp_ctx_destroy.restype = None
+        _lib.vp_ctx_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _ptr(x):
+    """Raw device pointer of a torch tensor / int / None."""
+    if x is None:
+        return C.c_void_p(None)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(type(x))
+
+
+def frame_params(cfg, sat_variant=SAT_TILED, order=ORDER_RASTER, sampler_mode=None) -> VpFrameParams:
+    p = VpFrameParams()
+    p.layout, p.qw, p.qh = cfg.layout, cfg.qw, cfg.qh
+    p.model = cfg.model()
+    p.max_robot_height, p.field_scale, p.off_x, p.off_y = cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y
+    p.fw, p.fh = cfg.fw, cfg.fh
+    p.grad_offset, p.circle_radius, p.list_radius = cfg.grad_offset, cfg.circle_radius, cfg.list_radius
+    p.circ_threshold, p.min_score, p.max_matches = cfg.circ_threshold, cfg.min_score, cfg.max_matches
+    p.sampler_mode = cfg.sampler_mode if sampler_mode is None else sampler_mode
+    p.sat_variant, p.order = sat_variant, order
+    return p
+
+
+class Context:
+    """VpContext wrapper.  `stream_ptr` adopts an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, n_streams=1, stream_ptr=None):
+        self.l = lib()
+        h = C.c_void_p()
+        if stream_ptr is None:
+            rc = self.l.vp_ctx_create(int(device), int(n_streams), C.byref(h))
+        else:
+            rc = self.l.vp_ctx_adopt_stream(int(device), C.c_void_p(stream_ptr), C.byref(h))
+        if rc != VP_OK:
+            raise VpError(rc, self.l.vp_last_error().decode())
+        self.h = h
+        self.n_streams = 1 if stream_ptr is not None else n_streams
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.l.vp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != VP_OK:
+            raise VpError(rc, self.l.vp_last_error().decode())
+
+    @property
+    def device_name(self):
+        return self.l.vp_device_name(self.h).decode()
+
+    def sync(self, stream=-1):
+        self._ck(self.l.vp_sync(self.h, int(stream)))
+
+    # ---- memory -----------------------------------------------------------------------------------------------------
+    def malloc(self, nbytes) -> int:
+        p = C.c_void_p()
+        self._ck(self.l.vp_malloc_device(self.h, C.c_size_t(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        self._ck(self.l.vp_free_device(self.h, C.c_void_p(dptr)))
+
+    def h2d(self, dptr, arr, stream=0):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.l.vp_copy_h2d(self.h, stream, _ptr(dptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+        self.sync(stream)  # pageable source: keep it alive until the copy is done
+
+    def d2h(self, dptr, shape, dtype, stream=0):
+        out = np.empty(shape, dtype)
+        self._ck(self.l.vp_copy_d2h_sync(self.h, stream, out.ctypes.data_as(C.c_void_p), _ptr(dptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def memset(self, dptr, value, nbytes, stream=0):
+        self._ck(self.l.vp_memset_device(self.h, stream, _ptr(dptr), int(value), C.c_size_t(nbytes)))
+
+    # ---- events -------------------------------------------------------------------------------------------------------
+    def events_enable(self, on=True):
+        self._ck(self.l.vp_events_enable(self.h, int(bool(on))))
+
+    def event_times(self, cap=4096):
+        buf = (VpStageTime * cap)()
+        n = self.l.vp_event_times(self.h, buf, cap)
+        if n < 0:
+            self._ck(n)
+        return [(buf[i].stage.decode(), float(buf[i].ms)) for i in range(n)]
+
+    def events_clear(self):
+        self._ck(self.l.vp_events_clear(self.h))
+
+    # ---- stages -------------------------------------------------------------------------------------------------------
+    def raw2quad(self, raw, layout, qw, qh, batch, planes, stream=0):
+        self._ck(self.l.vp_raw2quad(self.h, stream, _ptr(raw), int(layout), int(qw), int(qh), int(batch), _ptr(planes)))
+
+    def _resample(self, fn, src, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream):
+        self._ck(fn(self.h, stream, _ptr(src), int(layout), int(qw), int(qh), C.byref(model), C.c_float(height), C.c_float(fs), C.c_float(ox), C.c_float(oy),
+                    int(mode), int(fw), int(fh), int(batch), _ptr(flat)))
+
+    def resample(self, planes, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream=0):
+        self._resample(self.l.vp_resample, planes, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream)
+
+    def resample_raw(self, raw, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream=0):
+        self._resample(self.l.vp_resample_raw, raw, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream)
+
+    def graddot(self, flat, w, h, offset, batch, out, stream=0):
+        self._ck(self.l.vp_graddot(self.h, stream, _ptr(flat), int(w), int(h), int(offset), int(batch), _ptr(out)))
+
+    def sat(self, graddot, w, h, batch, variant, sat, stream=0):
+        self._ck(self.l.vp_sat(self.h, stream, _ptr(graddot), int(w), int(h), int(batch), int(variant), _ptr(sat)))
+
+    def graddot_sat(self, flat, w, h, offset, batch, variant, sat, graddot_out=None, stream=0):
+        self._ck(self.l.vp_graddot_sat(self.h, stream, _ptr(flat), int(w), int(h), int(offset), int(batch), int(variant), _ptr(sat), _ptr(graddot_out)))
+
+    def blobcenter(self, sat, w, h, radius, batch, out, stream=0):
+        self._ck(self.l.vp_blobcenter(self.h, stream, _ptr(sat), int(w), int(h), int(radius), int(batch), _ptr(out)))
+
+    def bloblist(self, flat, blobcenter, w, h, batch, thr, min_score, radius, max_matches, order, matches, idx, counter, stream=0):
+        self._ck(self.l.vp_bloblist(self.h, stream, _ptr(flat), _ptr(blobcenter), int(w), int(h), int(batch), C.c_float(thr), C.c_float(min_score), int(radius),
+                                    int(max_matches), int(order), _ptr(matches), _ptr(idx), _ptr(counter)))
+
+    def blobcenter_list(self, flat, sat, w, h, batch, circle_radius, thr, min_score, list_radius, max_matches, order, matches, idx, counter, blobcenter_out=None, stream=0):
+        self._ck(self.l.vp_blobcenter_list(self.h, stream, _ptr(flat), _ptr(sat), int(w), int(h), int(batch), int(circle_radius), C.c_float(thr), C.c_float(min_score),
+                                           int(list_radius), int(max_matches), int(order), _ptr(matches), _ptr(idx), _ptr(counter), _ptr(blobcenter_out)))
+
+    def blobscore(self, flat, blobcenter, w, h, batch, thr, radius, score, stream=0):
+        self._ck(self.l.vp_blobscore(self.h, stream, _ptr(flat), _ptr(blobcenter), int(w), int(h), int(batch), C.c_float(thr), int(radius), _ptr(score)))
+
+    def circularize(self, graddot, w, h, batch, min_r, max_r, out, stream=0):
+        self._ck(self.l.vp_circularize(self.h, stream, _ptr(graddot), int(w), int(h), int(batch), int(min_r), int(max_r), _ptr(out)))
+
+    def frame(self, params: VpFrameParams, raw, batch, flat, sat, matches, counter, idx=None, planes=None, graddot=None, blobcenter=None, stream=0):
+        b = VpFrameBuffers(_ptr(flat), _ptr(sat), _ptr(matches), _ptr(idx), _ptr(counter), _ptr(planes), _ptr(graddot), _ptr(blobcenter))
+        self._ck(self.l.vp_frame(self.h, stream, C.byref(params), _ptr(raw), int(batch), C.byref(b)))
+
+
+def sorted_blobs(matches_bytes, idx, counter, max_matches):
+    """Host view of one frame's list as (records sorted by pixel index, sorted idx): the order-independent parity key."""
+    n = min(int(counter[0]), max_matches)
+    m = np.frombuffer(np.ascontiguousarray(matches_bytes).tobytes(), MATCH_DTYPE)[:n]
+    idx = np.asarray(idx)[:n]
+    order = np.argsort(idx, kind="stable")
+    return m[order], idx[order]

@@ -1,0 +1,134 @@
+// Internal header of libvp_hip.so (gfx950 only): context, error plumbing, launch bookkeeping, device helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vp_hip.h"
+
+#define VP_MAX_STREAMS 16
+
+struct VpEventRec {
+	const char* stage;
+	hipEvent_t start, stop;
+};
+
+struct VpWorkspace {
+	void* ptr = nullptr;
+	size_t bytes = 0;
+};
+
+struct VpContext {
+	int device = 0;
+	int n_streams = 0;
+	bool own_streams = true;
+	hipStream_t streams[VP_MAX_STREAMS] = {};
+	VpWorkspace ws[VP_MAX_STREAMS];      // scratch that lives across calls (candidate lists, tile carries, sort temp)
+	uint32_t sat_epoch[VP_MAX_STREAMS] = {}; // generation tag of the single-pass SAT carry granules
+	int* host_flag[VP_MAX_STREAMS] = {};   // pinned word the SAT kernel raises on a look-back timeout
+	std::string device_name;
+	int cu_count = 0;
+	bool events_on = false;
+	std::mutex mu;
+	std::vector<VpEventRec> events;
+};
+
+void vp_set_error(const char* fmt, ...);
+
+#define VP_CHECK_HIP(expr)                                                                                     \
+	do {                                                                                                         \
+		hipError_t e_ = (expr);                                                                                  \
+		if(e_ != hipSuccess) {                                                                                   \
+			vp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);           \
+			return VP_ERR_HIP;                                                                                   \
+		}                                                                                                        \
+	} while(0)
+
+#define VP_REQUIRE(cond, ...)                                                                                  \
+	do {                                                                                                         \
+		if(!(cond)) {                                                                                            \
+			vp_set_error(__VA_ARGS__);                                                                           \
+			return VP_ERR_INVALID;                                                                               \
+		}                                                                                                        \
+	} while(0)
+
+#define VP_TRY(expr)                       \
+	do {                                     \
+		int rc_ = (expr);                    \
+		if(rc_ != VP_OK) return rc_;         \
+	} while(0)
+
+static inline int vp_check_ctx(VpContext* ctx, int stream) {
+	if(!ctx) {
+		vp_set_error("null context");
+		return VP_ERR_INVALID;
+	}
+	if(stream < 0 || stream >= ctx->n_streams) {
+		vp_set_error("stream %d out of range [0,%d)", stream, ctx->n_streams);
+		return VP_ERR_INVALID;
+	}
+	return VP_OK;
+}
+
+// Scratch of at least `bytes` on `stream`; grows (stream-synchronising) only when too small.
+int vp_workspace(VpContext* ctx, int stream, size_t bytes, void** out);
+
+// RAII bracket for per-stage hipEvent timing (the cl::Event list of opencl.h:84)
+struct VpStageTimer {
+	VpContext* ctx;
+	hipStream_t s;
+	const char* stage;
+	hipEvent_t start = nullptr, stop = nullptr;
+	VpStageTimer(VpContext* c, int stream, const char* name): ctx(c), s(c->streams[stream]), stage(name) {
+		if(ctx->events_on && hipEventCreate(&start) == hipSuccess && hipEventCreate(&stop) == hipSuccess) (void)hipEventRecord(start, s);
+	}
+	~VpStageTimer() {
+		if(start && stop) {
+			(void)hipEventRecord(stop, s);
+			std::lock_guard<std::mutex> g(ctx->mu);
+			ctx->events.push_back({stage, start, stop});
+		}
+	}
+};
+
+static inline int vp_launch_ok(const char* what) {
+	hipError_t e = hipGetLastError();
+	if(e != hipSuccess) {
+		vp_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+		return VP_ERR_HIP;
+	}
+	return VP_OK;
+}
+
+static inline unsigned vp_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// ---- device helpers ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// inclusive wave-64 prefix sum (wrapping int32)
+__device__ __forceinline__ int vp_wave_scan_incl(int v) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for(int d = 1; d < 64; d <<= 1) {
+		const int t = __shfl_up(v, d, 64);
+		if(lane >= d) v += t;
+	}
+	return v;
+}
+
+__device__ __forceinline__ int vp_wave_sum(int v) {
+#pragma unroll
+	for(int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+__device__ __forceinline__ unsigned vp_wave_sum_u(unsigned v) {
+#pragma unroll
+	for(int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}

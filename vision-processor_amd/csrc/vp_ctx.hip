@@ -1,0 +1,226 @@
+// Context / runtime layer of the C ABI: replaces the reference's OpenCL wrapper (src/opencl.{h,cpp}).
+//   OpenCL::OpenCL (device pick, one in-order profiling queue)   opencl.cpp:34-50   -> vp_ctx_create
+//   OpenCL::wait                                                   opencl.cpp:87-92   -> vp_sync
+//   OpenCL::printRuntimes / clearEvents                            opencl.cpp:94-105  -> vp_event_times / vp_events_clear
+//   clAlloc / CLArray / CLImage allocation, map/unmap              opencl.cpp:137-159 -> vp_malloc_* / vp_copy_*
+#include "vp_common.h"
+
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void vp_set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char* vp_last_error(void) { return g_err; }
+
+extern "C" int vp_device_count(void) {
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+static int ctx_init(int device, VpContext* ctx) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if(e != hipSuccess || n <= 0) {
+		vp_set_error("no HIP device available (%s): this library has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+		return VP_ERR_NODEVICE;
+	}
+	VP_REQUIRE(device >= 0 && device < n, "device %d out of range [0,%d)", device, n);
+	VP_CHECK_HIP(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	VP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+	ctx->device = device;
+	ctx->device_name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+	ctx->cu_count = prop.multiProcessorCount;
+	return VP_OK;
+}
+
+extern "C" int vp_ctx_create(int device, int n_streams, VpContext** out) {
+	VP_REQUIRE(out, "out is null");
+	VP_REQUIRE(n_streams >= 1 && n_streams <= VP_MAX_STREAMS, "n_streams %d out of range [1,%d]", n_streams, VP_MAX_STREAMS);
+	VpContext* ctx = new VpContext();
+	int rc = ctx_init(device, ctx);
+	if(rc != VP_OK) {
+		delete ctx;
+		return rc;
+	}
+	ctx->n_streams = n_streams;
+	for(int i = 0; i < n_streams; i++) {
+		if(hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking) != hipSuccess) {
+			vp_set_error("hipStreamCreate failed");
+			delete ctx;
+			return VP_ERR_HIP;
+		}
+	}
+	*out = ctx;
+	return VP_OK;
+}
+
+extern "C" int vp_ctx_adopt_stream(int device, void* hip_stream, VpContext** out) {
+	VP_REQUIRE(out, "out is null");
+	VpContext* ctx = new VpContext();
+	int rc = ctx_init(device, ctx);
+	if(rc != VP_OK) {
+		delete ctx;
+		return rc;
+	}
+	ctx->n_streams = 1;
+	ctx->own_streams = false;
+	ctx->streams[0] = (hipStream_t)hip_stream;
+	*out = ctx;
+	return VP_OK;
+}
+
+extern "C" void vp_ctx_destroy(VpContext* ctx) {
+	if(!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	for(int i = 0; i < ctx->n_streams; i++) {
+		(void)hipStreamSynchronize(ctx->streams[i]);
+		if(ctx->ws[i].ptr) (void)hipFree(ctx->ws[i].ptr);
+		if(ctx->host_flag[i]) (void)hipHostFree(ctx->host_flag[i]);
+		if(ctx->own_streams) (void)hipStreamDestroy(ctx->streams[i]);
+	}
+	for(auto& e : ctx->events) {
+		(void)hipEventDestroy(e.start);
+		(void)hipEventDestroy(e.stop);
+	}
+	delete ctx;
+}
+
+extern "C" const char* vp_device_name(VpContext* ctx) { return ctx ? ctx->device_name.c_str() : ""; }
+
+extern "C" int vp_sync(VpContext* ctx, int stream) {
+	VP_REQUIRE(ctx, "null context");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	if(stream < 0) {
+		for(int i = 0; i < ctx->n_streams; i++) VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[i]));
+		return VP_OK;
+	}
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
+	return VP_OK;
+}
+
+int vp_workspace(VpContext* ctx, int stream, size_t bytes, void** out) {
+	VpWorkspace& w = ctx->ws[stream];
+	if(w.bytes < bytes) {
+		VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
+		if(w.ptr) VP_CHECK_HIP(hipFree(w.ptr));
+		w.ptr = nullptr;
+		w.bytes = 0;
+		const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+		hipError_t e = hipMalloc(&w.ptr, want);
+		if(e != hipSuccess) {
+			vp_set_error("workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+			return VP_ERR_NOMEM;
+		}
+		w.bytes = want;
+		VP_CHECK_HIP(hipMemsetAsync(w.ptr, 0, want, ctx->streams[stream]));
+	}
+	*out = w.ptr;
+	return VP_OK;
+}
+
+// ---- events ---------------------------------------------------------------------------------------------------------
+extern "C" int vp_events_enable(VpContext* ctx, int on) {
+	VP_REQUIRE(ctx, "null context");
+	ctx->events_on = on != 0;
+	return VP_OK;
+}
+
+extern "C" int vp_event_times(VpContext* ctx, VpStageTime* out, int cap) {
+	VP_REQUIRE(ctx && (out || cap == 0), "bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	for(int i = 0; i < ctx->n_streams; i++) VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[i]));
+	std::lock_guard<std::mutex> g(ctx->mu);
+	int n = 0;
+	for(auto& e : ctx->events) {
+		if(n >= cap) break;
+		float ms = 0.f;
+		VP_CHECK_HIP(hipEventElapsedTime(&ms, e.start, e.stop));
+		out[n].stage = e.stage;
+		out[n].ms = ms;
+		n++;
+	}
+	return n;
+}
+
+extern "C" int vp_events_clear(VpContext* ctx) {
+	VP_REQUIRE(ctx, "null context");
+	std::lock_guard<std::mutex> g(ctx->mu);
+	for(auto& e : ctx->events) {
+		(void)hipEventDestroy(e.start);
+		(void)hipEventDestroy(e.stop);
+	}
+	ctx->events.clear();
+	return VP_OK;
+}
+
+// ---- memory ---------------------------------------------------------------------------------------------------------
+extern "C" int vp_malloc_device(VpContext* ctx, size_t bytes, void** dptr) {
+	VP_REQUIRE(ctx && dptr, "bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+	if(e != hipSuccess) {
+		vp_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+		return VP_ERR_NOMEM;
+	}
+	return VP_OK;
+}
+
+extern "C" int vp_free_device(VpContext* ctx, void* dptr) {
+	VP_REQUIRE(ctx, "null context");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	if(dptr) VP_CHECK_HIP(hipFree(dptr));
+	return VP_OK;
+}
+
+extern "C" int vp_malloc_host(VpContext* ctx, size_t bytes, void** hptr) {
+	VP_REQUIRE(ctx && hptr, "bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+	if(e != hipSuccess) {
+		vp_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+		return VP_ERR_NOMEM;
+	}
+	return VP_OK;
+}
+
+extern "C" int vp_free_host(VpContext* ctx, void* hptr) {
+	VP_REQUIRE(ctx, "null context");
+	if(hptr) VP_CHECK_HIP(hipHostFree(hptr));
+	return VP_OK;
+}
+
+extern "C" int vp_copy_h2d(VpContext* ctx, int stream, void* dst_d, const void* src_h, size_t bytes) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VP_CHECK_HIP(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, ctx->streams[stream]));
+	return VP_OK;
+}
+
+extern "C" int vp_copy_d2h(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VP_CHECK_HIP(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, ctx->streams[stream]));
+	return VP_OK;
+}
+
+extern "C" int vp_copy_d2h_sync(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes) {
+	VP_TRY(vp_copy_d2h(ctx, stream, dst_h, src_d, bytes));
+	VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
+	return VP_OK;
+}
+
+extern "C" int vp_memset_device(VpContext* ctx, int stream, void* dst_d, int value, size_t bytes) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VP_CHECK_HIP(hipMemsetAsync(dst_d, value, bytes, ctx->streams[stream]));
+	return VP_OK;
+}

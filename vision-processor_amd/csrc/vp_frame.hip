@@ -1,0 +1,21 @@
+// Whole-frame entry point: Resources::raw2quad (Resources.cpp:138-143) + Resources::rgba2blobCenter (:151-164) + the
+// blobList launch and counter protocol of main.cpp:283-289, for `batch` frames on one stream with no host sync inside.
+//
+// Hot path = three launches groups: [raw2quad+resampling fused] -> [gradientDot+SAT] -> [circle + blobList]; the four
+// quad planes, gradDot and blobCenter are only written when the caller asks for them as debug / stream views.
+#include "vp_common.h"
+
+extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(p && raw && b, "vp_frame: null pointer");
+	VP_REQUIRE(b->flat && b->sat && b->matches && b->counter, "vp_frame: flat, sat, matches and counter buffers are required");
+	if(b->planes) {
+		VP_TRY(vp_raw2quad(ctx, stream, raw, p->layout, p->qw, p->qh, batch, b->planes));
+		VP_TRY(vp_resample(ctx, stream, b->planes, p->layout, p->qw, p->qh, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->sampler_mode, p->fw, p->fh, batch, b->flat));
+	} else {
+		VP_TRY(vp_resample_raw(ctx, stream, raw, p->layout, p->qw, p->qh, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->sampler_mode, p->fw, p->fh, batch, b->flat));
+	}
+	VP_TRY(vp_graddot_sat(ctx, stream, b->flat, p->fw, p->fh, p->grad_offset, batch, p->sat_variant, b->sat, b->graddot));
+	return vp_blobcenter_list(ctx, stream, b->flat, b->sat, p->fw, p->fh, batch, p->circle_radius, p->circ_threshold, p->min_score, p->list_radius, p->max_matches, p->order,
+			b->matches, b->idx, b->counter, b->blobcenter);
+}

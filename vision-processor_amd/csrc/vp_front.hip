@@ -1,0 +1,205 @@
+// Front of the chain: Bayer de-interleave and field-plane reprojection.
+//   raw2quad   (raw2quad.cl:21-39, launched at Resources.cpp:142)
+//   resampling (resampling.cl:29-100, launched at Resources.cpp:159)
+//   + a fused form that reads the raw sensor buffer directly so the four planes never hit HBM.
+//
+// Numerics contract: field2image is evaluated in IEEE binary32, one rounding per source operation
+// in the order of resampling.cl:29-47,53; this file is built with -ffp-contract=off and HIP's default correctly
+// rounded fp32 division.  Integer-linear sampling follows VpSamplerMode (frozen in oracle/ref_shim.c).
+#include "vp_common.h"
+
+// ---------------------------------------------------------------- raw2quad ----------------------------------------
+// Bayer, vector path: one thread de-interleaves four 2x2 cells = 8 B of each of two sensor rows into 4 B per plane.
+__global__ __launch_bounds__(256) void k_raw2quad_bayer4(const uint8_t* __restrict__ raw, uint8_t* __restrict__ planes, int qw, int qh) {
+	const int x4 = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	if(x4 * 4 >= qw || y >= qh) return;
+	const size_t q = (size_t)qw * qh;
+	const uint8_t* fr = raw + (size_t)blockIdx.z * 4 * q;
+	const size_t row = 2 * (size_t)qw;
+	const uint2 a = *reinterpret_cast<const uint2*>(fr + (size_t)(2 * y) * row + 8 * (size_t)x4);
+	const uint2 b = *reinterpret_cast<const uint2*>(fr + (size_t)(2 * y + 1) * row + 8 * (size_t)x4);
+	// v_perm_b32: selector bytes 0-3 pick from the 2nd operand, 4-7 from the 1st
+	const uint32_t p0 = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u), p1 = __builtin_amdgcn_perm(a.y, a.x, 0x07050301u);
+	const uint32_t p2 = __builtin_amdgcn_perm(b.y, b.x, 0x06040200u), p3 = __builtin_amdgcn_perm(b.y, b.x, 0x07050301u);
+	uint8_t* out = planes + (size_t)blockIdx.z * 4 * q + (size_t)y * qw + 4 * (size_t)x4;
+	*reinterpret_cast<uint32_t*>(out) = p0;
+	*reinterpret_cast<uint32_t*>(out + q) = p1;
+	*reinterpret_cast<uint32_t*>(out + 2 * q) = p2;
+	*reinterpret_cast<uint32_t*>(out + 3 * q) = p3;
+}
+
+// any width / BGR: one thread per cell
+template<bool BGR>
+__global__ __launch_bounds__(256) void k_raw2quad_scalar(const uint8_t* __restrict__ raw, uint8_t* __restrict__ planes, int qw, int qh) {
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	if(x >= qw || y >= qh) return;
+	const size_t q = (size_t)qw * qh;
+	uint8_t* out = planes + (size_t)blockIdx.z * 4 * q + (size_t)y * qw + x;
+	if(BGR) {
+		const uint8_t* p = raw + (size_t)blockIdx.z * 3 * q + 3 * ((size_t)y * qw + x);
+		out[0] = p[0];
+		out[q] = p[1];
+		out[2 * q] = p[2];
+	} else {
+		const size_t row = 2 * (size_t)qw;
+		const uint8_t* p = raw + (size_t)blockIdx.z * 4 * q + (size_t)(2 * y) * row + 2 * (size_t)x;
+		out[0] = p[0];
+		out[q] = p[1];
+		out[2 * q] = p[row];
+		out[3 * q] = p[row + 1];
+	}
+}
+
+extern "C" int vp_raw2quad(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int batch, uint8_t* planes) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(raw && planes && qw > 0 && qh > 0 && batch > 0 && layout >= 0 && layout <= 2, "vp_raw2quad: bad arguments");
+	VP_REQUIRE(batch <= 65535, "vp_raw2quad: batch %d > 65535", batch);
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "raw2quad");
+	hipStream_t s = ctx->streams[stream];
+	const dim3 block(64, 4);
+	if(layout == VP_LAYOUT_BGR) {
+		k_raw2quad_scalar<true><<<dim3(vp_div_up(qw, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, planes, qw, qh);
+	} else if(qw % 4 == 0 && (reinterpret_cast<uintptr_t>(raw) & 7) == 0 && (reinterpret_cast<uintptr_t>(planes) & 3) == 0) {
+		k_raw2quad_bayer4<<<dim3(vp_div_up(qw / 4, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, planes, qw, qh);
+	} else {
+		k_raw2quad_scalar<false><<<dim3(vp_div_up(qw, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, planes, qw, qh);
+	}
+	return vp_launch_ok("raw2quad");
+}
+
+// ---------------------------------------------------------------- resampling --------------------------------------
+struct ResampleArgs {
+	VpCameraModel m;
+	float height, fs, ox, oy;
+	int qw, qh, fw, fh;
+};
+
+// resampling.cl:29-47
+__device__ __forceinline__ void field2image(const VpCameraModel& m, float fx, float fy, float fz, float& ox, float& oy) {
+	fx = fx - m.c[0];
+	fy = fy - m.c[1];
+	fz = fz - m.c[2];
+	const float cx = m.r[0] * fx + m.r[1] * fy + m.r[2] * fz;
+	const float cy = m.r[3] * fx + m.r[4] * fy + m.r[5] * fz;
+	const float cz = m.r[6] * fx + m.r[7] * fy + m.r[8] * fz;
+	const float x2 = cx / cz, y2 = cy / cz;
+	float ux = x2, uy = y2;
+#pragma unroll
+	for(int i = 0; i < 8; i++) {
+		const float rx = ux * ux, ry = uy * uy;
+		const float dr = 1.0f + m.d * (rx + ry);
+		ux = x2 / dr;
+		uy = y2 / dr;
+	}
+	ox = m.f * ux + m.p[0];
+	oy = m.f * uy + m.p[1];
+}
+
+// texel (i, j) of quad plane `ch`, either from materialised planes or straight from the raw sensor buffer
+template<int LAYOUT, bool FROM_RAW>
+__device__ __forceinline__ uint32_t texel(const uint8_t* __restrict__ src, int ch, int i, int j, int qw, int qh) {
+	if(!FROM_RAW) return src[(size_t)ch * qw * qh + (size_t)j * qw + i];
+	if(LAYOUT == VP_LAYOUT_BGR) return src[3 * ((size_t)j * qw + i) + ch];
+	return src[(size_t)(2 * j + (ch >> 1)) * (2 * (size_t)qw) + 2 * (size_t)i + (ch & 1)]; // raw2quad.cl:31-37
+}
+
+template<int LAYOUT, int MODE, bool FROM_RAW>
+__device__ __forceinline__ uint32_t sample(const uint8_t* __restrict__ src, int ch, float u, float v, int qw, int qh) {
+	if(MODE == VP_SAMPLER_NEAREST) {
+		const int x = vp_clampi((int)floorf(u), 0, qw - 1), y = vp_clampi((int)floorf(v), 0, qh - 1);
+		return texel<LAYOUT, FROM_RAW>(src, ch, x, y, qw, qh);
+	}
+	const float um = u - 0.5f, vm = v - 0.5f;
+	const float fu = floorf(um), fv = floorf(vm);
+	const float a = um - fu, b = vm - fv;
+	const int i0 = vp_clampi((int)fu, 0, qw - 1), i1 = vp_clampi((int)fu + 1, 0, qw - 1);
+	const int j0 = vp_clampi((int)fv, 0, qh - 1), j1 = vp_clampi((int)fv + 1, 0, qh - 1);
+	const float t00 = (float)texel<LAYOUT, FROM_RAW>(src, ch, i0, j0, qw, qh), t10 = (float)texel<LAYOUT, FROM_RAW>(src, ch, i1, j0, qw, qh);
+	const float t01 = (float)texel<LAYOUT, FROM_RAW>(src, ch, i0, j1, qw, qh), t11 = (float)texel<LAYOUT, FROM_RAW>(src, ch, i1, j1, qw, qh);
+	const float oma = 1.0f - a, omb = 1.0f - b;
+	const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+	float t = w00 * t00;
+	t = t + w10 * t10;
+	t = t + w01 * t01;
+	t = t + w11 * t11;
+	return (uint32_t)t;
+}
+
+template<int LAYOUT, int MODE, bool FROM_RAW>
+__global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ src, uint8_t* __restrict__ flat, const ResampleArgs a, size_t src_frame_bytes) {
+	const int gx = blockIdx.x * 64 + threadIdx.x;
+	const int gy = blockIdx.y * 4 + threadIdx.y;
+	if(gx >= a.fw || gy >= a.fh) return;
+	const uint8_t* s = src + (size_t)blockIdx.z * src_frame_bytes;
+	float px, py;
+	field2image(a.m, (float)gx * a.fs + a.ox, (float)gy * a.fs + a.oy, a.height, px, py); // resampling.cl:53
+	uint32_t r, g, b;
+	if(LAYOUT == VP_LAYOUT_BGR) { // :56-61
+		r = sample<LAYOUT, MODE, FROM_RAW>(s, 2, px, py, a.qw, a.qh);
+		g = sample<LAYOUT, MODE, FROM_RAW>(s, 1, px, py, a.qw, a.qh);
+		b = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px, py, a.qw, a.qh);
+	} else if(LAYOUT == VP_LAYOUT_RGGB) { // :64-71
+		r = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px + 0.25f, py + 0.25f, a.qw, a.qh);
+		g = sample<LAYOUT, MODE, FROM_RAW>(s, 1, px - 0.25f, py + 0.25f, a.qw, a.qh) / 2 + sample<LAYOUT, MODE, FROM_RAW>(s, 2, px + 0.25f, py - 0.25f, a.qw, a.qh) / 2;
+		b = sample<LAYOUT, MODE, FROM_RAW>(s, 3, px - 0.25f, py - 0.25f, a.qw, a.qh);
+	} else { // GRBG :74-79
+		r = sample<LAYOUT, MODE, FROM_RAW>(s, 1, px - 0.25f, py + 0.25f, a.qw, a.qh);
+		g = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px + 0.25f, py + 0.25f, a.qw, a.qh) / 2 + sample<LAYOUT, MODE, FROM_RAW>(s, 3, px - 0.25f, py - 0.25f, a.qw, a.qh) / 2;
+		b = sample<LAYOUT, MODE, FROM_RAW>(s, 2, px + 0.25f, py - 0.25f, a.qw, a.qh);
+	}
+	// delta-RGB in uint arithmetic (:86-91); each channel is at most (2*255+510)/4 = 255
+	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
+	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
+	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * a.fw * a.fh + (size_t)gy * a.fw + gx] = px4;
+}
+
+template<bool FROM_RAW>
+static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, int layout, int qw, int qh, const VpCameraModel* model,
+		float height, float fs, float ox, float oy, int mode, int fw, int fh, int batch, uint8_t* flat, const char* name) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(src && flat && model, "%s: null pointer", name);
+	VP_REQUIRE(qw > 0 && qh > 0 && fw > 0 && fh > 0 && batch > 0 && batch <= 65535, "%s: bad shape", name);
+	VP_REQUIRE(layout >= 0 && layout <= 2 && (mode == VP_SAMPLER_NEAREST || mode == VP_SAMPLER_BILINEAR_RTZ), "%s: bad layout/sampler mode", name);
+	VP_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 3) == 0, "%s: flat must be 4-byte aligned", name);
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, name);
+	ResampleArgs a;
+	a.m = *model;
+	a.height = height;
+	a.fs = fs;
+	a.ox = ox;
+	a.oy = oy;
+	a.qw = qw;
+	a.qh = qh;
+	a.fw = fw;
+	a.fh = fh;
+	const size_t q = (size_t)qw * qh;
+	const size_t frame_bytes = FROM_RAW ? (layout == VP_LAYOUT_BGR ? 3 * q : 4 * q) : 4 * q;
+	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), batch), block(64, 4);
+	hipStream_t s = ctx->streams[stream];
+#define VP_RS(L, M) k_resample<L, M, FROM_RAW><<<grid, block, 0, s>>>(src, flat, a, frame_bytes)
+	if(mode == VP_SAMPLER_NEAREST) {
+		if(layout == VP_LAYOUT_RGGB) VP_RS(VP_LAYOUT_RGGB, VP_SAMPLER_NEAREST);
+		else if(layout == VP_LAYOUT_GRBG) VP_RS(VP_LAYOUT_GRBG, VP_SAMPLER_NEAREST);
+		else VP_RS(VP_LAYOUT_BGR, VP_SAMPLER_NEAREST);
+	} else {
+		if(layout == VP_LAYOUT_RGGB) VP_RS(VP_LAYOUT_RGGB, VP_SAMPLER_BILINEAR_RTZ);
+		else if(layout == VP_LAYOUT_GRBG) VP_RS(VP_LAYOUT_GRBG, VP_SAMPLER_BILINEAR_RTZ);
+		else VP_RS(VP_LAYOUT_BGR, VP_SAMPLER_BILINEAR_RTZ);
+	}
+#undef VP_RS
+	return vp_launch_ok(name);
+}
+
+extern "C" int vp_resample(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, const VpCameraModel* model,
+		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat) {
+	return resample_dispatch<false>(ctx, stream, planes, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "resampling");
+}
+
+extern "C" int vp_resample_raw(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const VpCameraModel* model,
+		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat) {
+	return resample_dispatch<true>(ctx, stream, raw, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "raw2quad+resampling");
+}

@@ -1,0 +1,361 @@
+// Tail of the chain: ringness score from the SAT, thresholded local maxima, blob records.
+//   circle      (satBlobCenter.cl:34-42, Resources.cpp:163)
+//   matches     (blobList.cl:36-103, launched at main.cpp:289; counter protocol main.cpp:283-288,299-316)
+//   matches     (blobScore.cl:23-67, unlaunched in the reference)      -> vp_blobscore
+//   circularize (blobCenter.cl:29-63, never compiled by the reference)  -> vp_circularize
+//
+// The reference's `matches` does detection and the O(R^2) disc statistics in one divergent work-item.  Here the two are
+// split: a full-frame detect pass appends candidate pixel indices (wave-aggregated atomics), then an emit pass gives
+// each candidate a whole wavefront (64 lanes cover the disc, integer wave reductions => order-independent, exact).
+// Floating-point expressions keep the reference's evaluation order; sqrt and division are the correctly rounded
+// binary32 forms (HIP default), built with -ffp-contract=off.
+#include "vp_common.h"
+
+#include <cmath>
+
+// ---------------------------------------------------------------- circle -------------------------------------------
+__device__ __forceinline__ uint32_t sat_tap(const int32_t* __restrict__ s, int w, int h, int x, int y) {
+	return (uint32_t)s[(size_t)vp_clampi(y, 0, h - 1) * w + vp_clampi(x, 0, w - 1)];
+}
+
+// satBlobCenter.cl:37-41 with wrapping integer box sums (exact), converted once to binary32
+__device__ __forceinline__ float circle_at(const int32_t* __restrict__ s, int w, int h, int x, int y, int r, float div) {
+	const float pp = (float)(int32_t)(sat_tap(s, w, h, x + r, y + r) - sat_tap(s, w, h, x + r, y + 1) - sat_tap(s, w, h, x + 1, y + r) + sat_tap(s, w, h, x + 1, y + 1));
+	const float pn = (float)(int32_t)(sat_tap(s, w, h, x + r, y - r) - sat_tap(s, w, h, x + r, y - 1) - sat_tap(s, w, h, x + 1, y - r) + sat_tap(s, w, h, x + 1, y - 1));
+	const float np = (float)(int32_t)(sat_tap(s, w, h, x - r, y + r) - sat_tap(s, w, h, x - r, y + 1) - sat_tap(s, w, h, x - 1, y + r) + sat_tap(s, w, h, x - 1, y + 1));
+	const float nn = (float)(int32_t)(sat_tap(s, w, h, x - r, y - r) - sat_tap(s, w, h, x - r, y - 1) - sat_tap(s, w, h, x - 1, y - r) + sat_tap(s, w, h, x - 1, y - 1));
+	const float a = nn < pp ? nn : pp; // OpenCL min(x, y) = y < x ? y : x
+	const float b = np < pn ? np : pn;
+	return (b < a ? b : a) / div;
+}
+
+__global__ __launch_bounds__(256) void k_circle(const int32_t* __restrict__ sat, float* __restrict__ out, int w, int h, int r) {
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	if(x >= w || y >= h) return;
+	const size_t frame = (size_t)blockIdx.z * w * h;
+	out[frame + (size_t)y * w + x] = circle_at(sat + frame, w, h, x, y, r, (float)(r * r));
+}
+
+static int launch_circle(VpContext* ctx, int stream, const int32_t* sat, int w, int h, int radius, int batch, float* out) {
+	k_circle<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, ctx->streams[stream]>>>(sat, out, w, h, radius);
+	return vp_launch_ok("circle");
+}
+
+extern "C" int vp_blobcenter(VpContext* ctx, int stream, const int32_t* sat, int w, int h, int radius, int batch, float* blobcenter) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(sat && blobcenter && w > 0 && h > 0 && batch > 0 && batch <= 65535 && radius >= 0, "vp_blobcenter: bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "satBlobCenter");
+	return launch_circle(ctx, stream, sat, w, h, radius, batch, blobcenter);
+}
+
+// ---------------------------------------------------------------- blobList -----------------------------------------
+struct ListScratch {
+	uint32_t* cand;       // batch x n   candidate pixel indices
+	int32_t* cand_count;  // batch
+	uint32_t* idx;        // batch x max  (internal idx when the caller passes none)
+	uint32_t* idx_tmp;    // batch x max
+	uint8_t* rec_tmp;     // batch x max x 22
+	float* blobcenter;    // batch x n, only when the fused entry point has to materialise it itself
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+static int list_scratch(VpContext* ctx, int stream, size_t n, int batch, int max_matches, bool need_bc, ListScratch* s) {
+	const size_t b_cand = align256(sizeof(uint32_t) * n * batch), b_cnt = align256(sizeof(int32_t) * batch);
+	const size_t b_idx = align256(sizeof(uint32_t) * (size_t)max_matches * batch), b_rec = align256((size_t)22 * max_matches * batch);
+	const size_t b_bc = need_bc ? align256(sizeof(float) * n * batch) : 0;
+	void* base = nullptr;
+	VP_TRY(vp_workspace(ctx, stream, b_cand + b_cnt + 2 * b_idx + b_rec + b_bc, &base));
+	uint8_t* p = static_cast<uint8_t*>(base);
+	s->cand = reinterpret_cast<uint32_t*>(p); p += b_cand;
+	s->cand_count = reinterpret_cast<int32_t*>(p); p += b_cnt;
+	s->idx = reinterpret_cast<uint32_t*>(p); p += b_idx;
+	s->idx_tmp = reinterpret_cast<uint32_t*>(p); p += b_idx;
+	s->rec_tmp = p; p += b_rec;
+	s->blobcenter = need_bc ? reinterpret_cast<float*>(p) : nullptr;
+	return VP_OK;
+}
+
+__device__ __forceinline__ float bc_tap(const float* __restrict__ c, int w, int h, int x, int y) {
+	return c[(size_t)vp_clampi(y, 0, h - 1) * w + vp_clampi(x, 0, w - 1)];
+}
+
+// blobList.cl:37-55: threshold, 4-neighbour strict-'>' peak test
+__global__ __launch_bounds__(256) void k_detect(const float* __restrict__ circ, uint32_t* __restrict__ cand, int32_t* __restrict__ cand_count,
+		int32_t* __restrict__ counter, int w, int h, float thr) {
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	if(x >= w || y >= h) return;
+	const int z = blockIdx.z;
+	const size_t n = (size_t)w * h;
+	const float* c = circ + z * n;
+	const float v = c[(size_t)y * w + x];
+	if(v < thr) return;
+	if(bc_tap(c, w, h, x - 1, y) > v || bc_tap(c, w, h, x + 1, y) > v || bc_tap(c, w, h, x, y - 1) > v || bc_tap(c, w, h, x, y + 1) > v) {
+		atomicAdd(&counter[3 * z + 2], 1);
+		return;
+	}
+	const int slot = atomicAdd(&cand_count[z], 1);
+	cand[z * n + slot] = (uint32_t)(y * w + x);
+}
+
+__device__ __forceinline__ void store_match(uint8_t* dst, float x, float y, const uint32_t color[3], uint32_t center, float circ, float score) {
+	// 22-byte packed record (blobList.cl:26-32): only 2-byte alignment is guaranteed
+	uint16_t* d = reinterpret_cast<uint16_t*>(dst);
+	const uint32_t xb = __float_as_uint(x), yb = __float_as_uint(y), cb = __float_as_uint(circ), sb = __float_as_uint(score);
+	d[0] = (uint16_t)xb; d[1] = (uint16_t)(xb >> 16);
+	d[2] = (uint16_t)yb; d[3] = (uint16_t)(yb >> 16);
+	d[4] = (uint16_t)(color[0] | (color[1] << 8));
+	d[5] = (uint16_t)(color[2] | ((center & 0xFF) << 8));
+	d[6] = (uint16_t)(((center >> 8) & 0xFF) | (((center >> 16) & 0xFF) << 8));
+	d[7] = (uint16_t)cb; d[8] = (uint16_t)(cb >> 16);
+	d[9] = (uint16_t)sb; d[10] = (uint16_t)(sb >> 16);
+}
+
+// disc statistics of blobList.cl:57-78 by one wavefront; all lanes return the same values
+__device__ __forceinline__ float disc_score_wave(const uint32_t* __restrict__ f, int w, int h, int px, int py, int radius, float circ, uint32_t color[3]) {
+	const int lane = threadIdx.x & 63;
+	const int D = 2 * radius + 1, sq = radius * radius;
+	uint32_t s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, n = 0;
+	for(int k = lane; k < D * D; k += 64) {
+		const int dy = k / D - radius, dx = k % D - radius;
+		if(dx * dx + dy * dy <= sq) {
+			const uint32_t v = f[(size_t)vp_clampi(py + dy, 0, h - 1) * w + vp_clampi(px + dx, 0, w - 1)];
+#pragma unroll
+			for(int c = 0; c < 3; c++) {
+				const uint32_t b = (v >> (8 * c)) & 0xFF;
+				s1[c] += b;
+				s2[c] += b * b;
+			}
+			n++;
+		}
+	}
+	n = vp_wave_sum_u(n);
+	const float nf = (float)(int)n;
+	float sd[3];
+#pragma unroll
+	for(int c = 0; c < 3; c++) {
+		s1[c] = vp_wave_sum_u(s1[c]);
+		s2[c] = vp_wave_sum_u(s2[c]);
+		const float a = (float)s1[c];
+		const float q = a * a / nf;
+		sd[c] = sqrtf(((float)s2[c] - q) / nf); // :76 (native_sqrt -> IEEE sqrt)
+		color[c] = s1[c] / n;                    // :96 uint division
+	}
+	return circ / (sd[0] + sd[1] + sd[2]);       // :78
+}
+
+// blobList.cl:57-102, one wavefront per candidate
+__global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat, const float* __restrict__ circ, const uint32_t* __restrict__ cand,
+		const int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, uint8_t* __restrict__ matches, uint32_t* __restrict__ idx_out,
+		int w, int h, float min_score, int radius, int max_matches) {
+	const int z = blockIdx.y;
+	const size_t n = (size_t)w * h;
+	const uint32_t* f = flat + z * n;
+	const float* c = circ + z * n;
+	const int lane = threadIdx.x & 63;
+	const int total = cand_count[z];
+	for(int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < total; k += gridDim.x * 4) {
+		const uint32_t pix = cand[z * n + k];
+		const int px = (int)(pix % (uint32_t)w), py = (int)(pix / (uint32_t)w);
+		const float v = c[pix];
+		uint32_t color[3];
+		const float score = disc_score_wave(f, w, h, px, py, radius, v, color);
+		if(lane != 0) continue;
+		if(score < min_score) { // :79-82 (NaN is kept)
+			atomicAdd(&counter[3 * z + 1], 1);
+			continue;
+		}
+		const int i = atomicAdd(&counter[3 * z], 1); // :87
+		if(i >= max_matches) continue;               // :88-89
+		const float nx = bc_tap(c, w, h, px - 1, py), qx = bc_tap(c, w, h, px + 1, py);
+		const float ny = bc_tap(c, w, h, px, py - 1), qy = bc_tap(c, w, h, px, py + 1);
+		const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
+		const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
+		store_match(matches + ((size_t)z * max_matches + i) * 22, mx, my, color, f[pix], v, score);
+		idx_out[(size_t)z * max_matches + i] = pix;
+	}
+}
+
+// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique)
+__global__ __launch_bounds__(256) void k_rank_scatter(const uint8_t* __restrict__ rec, const uint32_t* __restrict__ idx, const int32_t* __restrict__ counter,
+		uint8_t* __restrict__ rec_tmp, uint32_t* __restrict__ idx_tmp, int max_matches) {
+	__shared__ uint32_t tile[256];
+	const int z = blockIdx.y;
+	const int n = min(counter[3 * z], max_matches);
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t* id = idx + (size_t)z * max_matches;
+	const uint32_t mine = t < n ? id[t] : 0;
+	int rank = 0;
+	for(int j0 = 0; j0 < n; j0 += 256) {
+		const int j = j0 + threadIdx.x;
+		tile[threadIdx.x] = j < n ? id[j] : 0xFFFFFFFFu;
+		__syncthreads();
+		const int m = min(256, n - j0);
+		for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
+		__syncthreads();
+	}
+	if(t < n) {
+		const uint16_t* src = reinterpret_cast<const uint16_t*>(rec + ((size_t)z * max_matches + t) * 22);
+		uint16_t* dst = reinterpret_cast<uint16_t*>(rec_tmp + ((size_t)z * max_matches + rank) * 22);
+#pragma unroll
+		for(int k = 0; k < 11; k++) dst[k] = src[k];
+		idx_tmp[(size_t)z * max_matches + rank] = mine;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_copy_back(const uint8_t* __restrict__ rec_tmp, const uint32_t* __restrict__ idx_tmp, const int32_t* __restrict__ counter,
+		uint8_t* __restrict__ rec, uint32_t* __restrict__ idx, int max_matches) {
+	const int z = blockIdx.y;
+	const int n = min(counter[3 * z], max_matches);
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if(t >= n) return;
+	const uint16_t* src = reinterpret_cast<const uint16_t*>(rec_tmp + ((size_t)z * max_matches + t) * 22);
+	uint16_t* dst = reinterpret_cast<uint16_t*>(rec + ((size_t)z * max_matches + t) * 22);
+#pragma unroll
+	for(int k = 0; k < 11; k++) dst[k] = src[k];
+	if(idx) idx[(size_t)z * max_matches + t] = idx_tmp[(size_t)z * max_matches + t];
+}
+
+static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch, float thr, float min_score,
+		int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, const ListScratch& ws) {
+	hipStream_t s = ctx->streams[stream];
+	VP_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t) * 3 * batch, s)); // main.cpp:283-288
+	VP_CHECK_HIP(hipMemsetAsync(ws.cand_count, 0, sizeof(int32_t) * batch, s));
+	k_detect<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, s>>>(blobcenter, ws.cand, ws.cand_count, counter, w, h, thr);
+	VP_TRY(vp_launch_ok("blobList detect"));
+	uint32_t* idx_work = (order == VP_ORDER_RASTER || !idx) ? ws.idx : idx;
+	k_emit<<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
+			w, h, min_score, radius, max_matches);
+	VP_TRY(vp_launch_ok("blobList emit"));
+	if(order == VP_ORDER_RASTER) {
+		const dim3 grid(vp_div_up(max_matches, 256), batch);
+		k_rank_scatter<<<grid, 256, 0, s>>>(reinterpret_cast<const uint8_t*>(matches), ws.idx, counter, ws.rec_tmp, ws.idx_tmp, max_matches);
+		VP_TRY(vp_launch_ok("blobList rank"));
+		k_copy_back<<<grid, 256, 0, s>>>(ws.rec_tmp, ws.idx_tmp, counter, reinterpret_cast<uint8_t*>(matches), idx, max_matches);
+		VP_TRY(vp_launch_ok("blobList copy"));
+	}
+	return VP_OK;
+}
+
+static int list_args_ok(const char* name, const void* flat, const void* src, int w, int h, int batch, int radius, int max_matches, int order, const void* matches, const void* counter) {
+	VP_REQUIRE(flat && src && matches && counter, "%s: null pointer", name);
+	VP_REQUIRE(w > 0 && h > 0 && batch > 0 && batch <= 65535 && radius >= 0 && max_matches > 0, "%s: bad shape", name);
+	VP_REQUIRE((size_t)w * h < (size_t(1) << 31), "%s: frame too large", name);
+	VP_REQUIRE(order == VP_ORDER_ATOMIC || order == VP_ORDER_RASTER, "%s: bad order", name);
+	VP_REQUIRE((reinterpret_cast<uintptr_t>(matches) & 1) == 0, "%s: matches must be 2-byte aligned", name);
+	return VP_OK;
+}
+
+extern "C" int vp_bloblist(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch,
+		float circ_threshold, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_TRY(list_args_ok("vp_bloblist", flat, blobcenter, w, h, batch, radius, max_matches, order, matches, counter));
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	ListScratch ws;
+	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, false, &ws));
+	VpStageTimer t(ctx, stream, "blobList");
+	return list_from_blobcenter(ctx, stream, flat, blobcenter, w, h, batch, circ_threshold, min_score, radius, max_matches, order, matches, idx, counter, ws);
+}
+
+extern "C" int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* flat, const int32_t* sat, int w, int h, int batch,
+		int circle_radius, float circ_threshold, float min_score, int list_radius, int max_matches, int order,
+		VpMatch* matches, uint32_t* idx, int32_t* counter, float* blobcenter_out) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_TRY(list_args_ok("vp_blobcenter_list", flat, sat, w, h, batch, list_radius, max_matches, order, matches, counter));
+	VP_REQUIRE(circle_radius >= 0, "vp_blobcenter_list: bad circle radius");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	ListScratch ws;
+	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, blobcenter_out == nullptr, &ws));
+	VpStageTimer t(ctx, stream, "satBlobCenter+blobList");
+	float* bc = blobcenter_out ? blobcenter_out : ws.blobcenter;
+	VP_TRY(launch_circle(ctx, stream, sat, w, h, circle_radius, batch, bc));
+	return list_from_blobcenter(ctx, stream, flat, bc, w, h, batch, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter, ws);
+}
+
+// ---------------------------------------------------------------- validation kernels -------------------------------
+// blobScore.cl:23-67 -- per-pixel score image, -INFINITY where rejected.  One work-item per pixel like the reference.
+__global__ __launch_bounds__(256) void k_blobscore(const uint32_t* __restrict__ flat, const float* __restrict__ circ, float* __restrict__ score, int w, int h, float thr, int radius) {
+	const int x = blockIdx.x * 64 + threadIdx.x;
+	const int y = blockIdx.y * 4 + threadIdx.y;
+	if(x >= w || y >= h) return;
+	const size_t frame = (size_t)blockIdx.z * w * h;
+	const float* c = circ + frame;
+	const uint32_t* f = flat + frame;
+	const float v = c[(size_t)y * w + x];
+	float out = -INFINITY;
+	if(!(v < thr) && !(bc_tap(c, w, h, x - 1, y) > v || bc_tap(c, w, h, x + 1, y) > v || bc_tap(c, w, h, x, y - 1) > v || bc_tap(c, w, h, x, y + 1) > v)) {
+		uint32_t s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+		int n = 0;
+		const int sq = radius * radius;
+		for(int dy = -radius; dy <= radius; dy++)
+			for(int dx = -radius; dx <= radius; dx++)
+				if(dx * dx + dy * dy <= sq) {
+					const uint32_t p = f[(size_t)vp_clampi(y + dy, 0, h - 1) * w + vp_clampi(x + dx, 0, w - 1)];
+#pragma unroll
+					for(int k = 0; k < 3; k++) {
+						const uint32_t b = (p >> (8 * k)) & 0xFF;
+						s1[k] += b;
+						s2[k] += b * b;
+					}
+					n++;
+				}
+		const float nf = (float)n;
+		float sd[3];
+#pragma unroll
+		for(int k = 0; k < 3; k++) {
+			const float a = (float)s1[k];
+			const float q = a * a / nf;
+			sd[k] = sqrtf(((float)s2[k] - q) / nf);
+		}
+		out = v / (sd[0] + sd[1] + sd[2]);
+	}
+	score[frame + (size_t)y * w + x] = out;
+}
+
+extern "C" int vp_blobscore(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch, float circ_threshold, int radius, float* score) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(flat && blobcenter && score && w > 0 && h > 0 && batch > 0 && batch <= 65535 && radius >= 0, "vp_blobscore: bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "blobScore");
+	k_blobscore<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, ctx->streams[stream]>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, score, w, h, circ_threshold, radius);
+	return vp_launch_ok("blobScore");
+}
+
+// blobCenter.cl:29-63 -- quadrant means over quarter discs, sequential binary32 accumulation in the reference's loop order
+__global__ __launch_bounds__(256) void k_circularize(const float* __restrict__ g, float* __restrict__ out, int w, int h, int maxr) {
+	const int px = blockIdx.x * 64 + threadIdx.x;
+	const int py = blockIdx.y * 4 + threadIdx.y;
+	if(px >= w || py >= h) return;
+	const size_t frame = (size_t)blockIdx.z * w * h;
+	const float* c = g + frame;
+	const float sq = ((float)maxr + 0.5f) * ((float)maxr + 0.5f);
+	int n = 0;
+	float pp = 0.f, pn = 0.f, np = 0.f, nn = 0.f;
+	for(int y = 1; y <= maxr; y++)
+		for(int x = 1; x <= maxr; x++)
+			if((float)(x * x + y * y) <= sq) {
+				np += bc_tap(c, w, h, px - x, py + y);
+				pp += bc_tap(c, w, h, px + x, py + y);
+				nn += bc_tap(c, w, h, px - x, py - y);
+				pn += bc_tap(c, w, h, px + x, py - y);
+				n++;
+			}
+	const float nf = (float)n;
+	pp /= nf; nn /= nf; pn /= nf; np /= nf;
+	const float a = nn < pp ? nn : pp;
+	const float b = (-np) < (-pn) ? (-np) : (-pn);
+	out[frame + (size_t)py * w + px] = b < a ? b : a;
+}
+
+extern "C" int vp_circularize(VpContext* ctx, int stream, const float* graddot, int w, int h, int batch, int min_radius, int max_radius, float* out) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(graddot && out && w > 0 && h > 0 && batch > 0 && batch <= 65535 && max_radius >= 0, "vp_circularize: bad arguments");
+	(void)min_radius; // unused by the kernel body as well (blobCenter.cl:37-45 is commented out)
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "blobCenter(legacy)");
+	k_circularize<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, ctx->streams[stream]>>>(graddot, out, w, h, max_radius);
+	return vp_launch_ok("circularize");
+}
