@@ -28,15 +28,36 @@ from _vp_pkg import load  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask, capped at 64 worker threads."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+            break
+        except Exception:
+            continue
+    if n > 64:
+        n = 16  # a GPU box exposes every host CPU in the mask but grants one GPU a 16-core share
+    return n
+
+
 def cpu_baseline(cfg, seconds):
     """The oracle is used here only as the timed CPU baseline (kind 'port'), never as part of the measured GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     port = O.Port(threads=cores)
     model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
     raws = [cfg.synth(1000 + i) for i in range(4)]

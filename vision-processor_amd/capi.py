@@ -56,6 +56,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(HIP_SO):
             raise FileNotFoundError(f"{HIP_SO} missing: the HIP extension is required (run `make hip` / __graft_entry__.build()); there is no fallback")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing it first makes libvp_hip.so bind to
+        # that copy instead of pulling /opt/rocm's next to it (two runtimes in one process lose the device).
+        import torch  # noqa: F401
         _lib = C.CDLL(HIP_SO)
         _lib.vp_last_error.restype = C.c_char_p
         _lib.vp_device_name.restype = C.c_char_p

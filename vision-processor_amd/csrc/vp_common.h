@@ -29,9 +29,10 @@ struct VpContext {
 	int n_streams = 0;
 	bool own_streams = true;
 	hipStream_t streams[VP_MAX_STREAMS] = {};
-	VpWorkspace ws[VP_MAX_STREAMS];      // scratch that lives across calls (candidate lists, tile carries, sort temp)
-	uint32_t sat_epoch[VP_MAX_STREAMS] = {}; // generation tag of the single-pass SAT carry granules
-	int* host_flag[VP_MAX_STREAMS] = {};   // pinned word the SAT kernel raises on a look-back timeout
+	VpWorkspace ws[2][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries
+	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // generation tag of the single-pass SAT carry granules
+	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tiles handed out by all earlier launches on this stream (mod 2^32)
+	int* host_flag[VP_MAX_STREAMS] = {};           // pinned, device-mapped word the SAT kernel raises on a look-back timeout
 	std::string device_name;
 	int cu_count = 0;
 	bool events_on = false;
@@ -76,8 +77,9 @@ static inline int vp_check_ctx(VpContext* ctx, int stream) {
 	return VP_OK;
 }
 
-// Scratch of at least `bytes` on `stream`; grows (stream-synchronising) only when too small.
-int vp_workspace(VpContext* ctx, int stream, size_t bytes, void** out);
+// Scratch of at least `bytes` on `stream` in `slot`; grows (stream-synchronising, zero-filled) only when too small.
+// *grew (optional) tells the caller that persistent contents were lost.
+int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out, bool* grew = nullptr);
 
 // RAII bracket for per-stage hipEvent timing (the cl::Event list of opencl.h:84)
 struct VpStageTimer {

@@ -82,7 +82,8 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 	(void)hipSetDevice(ctx->device);
 	for(int i = 0; i < ctx->n_streams; i++) {
 		(void)hipStreamSynchronize(ctx->streams[i]);
-		if(ctx->ws[i].ptr) (void)hipFree(ctx->ws[i].ptr);
+		for(int k = 0; k < 2; k++)
+			if(ctx->ws[k][i].ptr) (void)hipFree(ctx->ws[k][i].ptr);
 		if(ctx->host_flag[i]) (void)hipHostFree(ctx->host_flag[i]);
 		if(ctx->own_streams) (void)hipStreamDestroy(ctx->streams[i]);
 	}
@@ -95,21 +96,34 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 
 extern "C" const char* vp_device_name(VpContext* ctx) { return ctx ? ctx->device_name.c_str() : ""; }
 
+// a raised flag means a bounded look-back wait of the single-pass SAT expired: the results of that launch are invalid
+int vp_check_timeout(VpContext* ctx, int stream) {
+	int* f = ctx->host_flag[stream];
+	if(f && *reinterpret_cast<volatile int*>(f) != 0) {
+		vp_set_error("single-pass SAT: a tile carry never arrived (bounded look-back wait expired) on stream %d", stream);
+		return VP_ERR_TIMEOUT;
+	}
+	return VP_OK;
+}
+
 extern "C" int vp_sync(VpContext* ctx, int stream) {
 	VP_REQUIRE(ctx, "null context");
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	if(stream < 0) {
 		for(int i = 0; i < ctx->n_streams; i++) VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[i]));
+		for(int i = 0; i < ctx->n_streams; i++) VP_TRY(vp_check_timeout(ctx, i));
 		return VP_OK;
 	}
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
-	return VP_OK;
+	return vp_check_timeout(ctx, stream);
 }
 
-int vp_workspace(VpContext* ctx, int stream, size_t bytes, void** out) {
-	VpWorkspace& w = ctx->ws[stream];
+int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out, bool* grew) {
+	VpWorkspace& w = ctx->ws[slot][stream];
+	if(grew) *grew = false;
 	if(w.bytes < bytes) {
+		if(grew) *grew = true;
 		VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
 		if(w.ptr) VP_CHECK_HIP(hipFree(w.ptr));
 		w.ptr = nullptr;

@@ -67,7 +67,7 @@ static int list_scratch(VpContext* ctx, int stream, size_t n, int batch, int max
 	const size_t b_idx = align256(sizeof(uint32_t) * (size_t)max_matches * batch), b_rec = align256((size_t)22 * max_matches * batch);
 	const size_t b_bc = need_bc ? align256(sizeof(float) * n * batch) : 0;
 	void* base = nullptr;
-	VP_TRY(vp_workspace(ctx, stream, b_cand + b_cnt + 2 * b_idx + b_rec + b_bc, &base));
+	VP_TRY(vp_workspace(ctx, stream, 0, b_cand + b_cnt + 2 * b_idx + b_rec + b_bc, &base));
 	uint8_t* p = static_cast<uint8_t*>(base);
 	s->cand = reinterpret_cast<uint32_t*>(p); p += b_cand;
 	s->cand_count = reinterpret_cast<int32_t*>(p); p += b_cnt;
