@@ -31,7 +31,8 @@ struct VpContext {
 	hipStream_t streams[VP_MAX_STREAMS] = {};
 	VpWorkspace ws[2][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries
 	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // generation tag of the single-pass SAT carry granules
-	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tiles handed out by all earlier launches on this stream (mod 2^32)
+	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tickets handed out per frame queue by all earlier launches on this stream (mod 2^32)
+	uint64_t sat_shape[VP_MAX_STREAMS] = {};       // tiling + batch those counters were advanced with
 	int* host_flag[VP_MAX_STREAMS] = {};           // pinned, device-mapped word the SAT kernel raises on a look-back timeout
 	std::string device_name;
 	int cu_count = 0;
