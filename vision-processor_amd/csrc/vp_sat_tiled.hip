@@ -149,6 +149,18 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 //
 // LDS image of a tile: interior I[rows][64] dwords (rows = TH + 2o, one 256-B row per 16 lanes => a wave instruction of
 // 16 B per lane lands 4 rows contiguously, which is what LDS-DMA requires) followed by the halo columns Hh[rows][2o].
+// Same walk, but the two nearest predecessors were polled EARLY (pre0 = 1 back, pre1 = 2 back, loaded at the top of the
+// tile, before its own sums exist): with the anti-diagonal order they are nearly always inclusive by now, so the carry
+// resolves without a memory round trip on the critical path.  `resolved` tells the caller it may skip the aggregate state.
+__device__ __forceinline__ bool early_resolve(u64 pre0, u64 pre1, int npred, const TiledArgs& a, int& carry) {
+	const uint32_t t0 = (uint32_t)(pre0 >> 32), t1 = (uint32_t)(pre1 >> 32);
+	const bool r0 = (t0 >> 2) == a.epoch && (t0 & 3u) != 0;
+	const bool inc0 = r0 && (t0 & 3u) == ST_INC;
+	const bool inc1 = npred >= 2 && (t1 >> 2) == a.epoch && (t1 & 3u) == ST_INC;
+	carry = (int)(uint32_t)pre0 + (inc0 ? 0 : (int)(uint32_t)pre1);
+	return __all(inc0 || (r0 && inc1)) && !(a.debug & 32);
+}
+
 template<int MODE>
 __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
 	constexpr bool FUSED = MODE != 0;
@@ -215,7 +227,10 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 		}
 	}
 
+	unsigned long long ph[5] = {0, 0, 0, 0, 0};
+	const bool stamp = (a.debug & 8) && lane == 0 && (wv == 0 || wv == 3);
 	for(;;) {
+		const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		const uint32_t tcur = a.order[rem];
 		const int ti = (int)(tcur >> 16), tj = (int)(tcur & 0xFFFF);
 		const int x0 = tj * TW, y0 = ti * TH;
@@ -241,6 +256,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 		}
 		if(loader) misc[3] = (int)(pending - a.ticket_base); // requested a whole tile ago: long since returned
 		__syncthreads();
+		const unsigned long long ts1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		if(loader) pending = atomicAdd(queue, 1u); // after the draining barrier, so nobody waits for it
 		const int next = misc[3];
 		const bool more = next >= 0 && next < perFrame;
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			T[wv * TW + lane] = run;
 		}
 		lds_barrier();
+		const unsigned long long ts2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
 		// ---- C/D: aggregates, publication, look-back (waves 0-2); wave 3 streams the next tile into LDS meanwhile ------
 		const size_t tile = (size_t)f * perFrame + (size_t)ti * a.tilesX + tj; // granules are indexed by grid position
@@ -319,7 +336,9 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 				}
 			}
 		}
+		const unsigned long long ts3a = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		lds_barrier();
+		const unsigned long long ts3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		const int K = misc[1];
 		if(wv == 1 && lane == 0 && ti > 0) st_granule(a.K + tile, a.epoch, ST_INC, K + misc[2]);
 
@@ -356,11 +375,278 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 				}
 			}
 		}
+		if(stamp) {
+			const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+			ph[0] += ts1 - ts0; ph[1] += ts2 - ts1; ph[2] += ts3a - ts2; ph[3] += ts3 - ts3a; ph[4] += ts4 - ts3;
+		}
 		if(!more) break;
 		rem = next;
 		lds_barrier(); // S/T/Av/Bv/misc of this tile are dead only now
 	}
 	(void)staged;
+	if(stamp) {
+		unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.ctrl + 16 + 16 * a.batch) + (wv == 3 ? 8 : 0);
+		for(int k = 0; k < 5; k++) atomicAdd(acc + k, ph[k]);
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast path (compile-time gradient offset O in 1..4, w % 64 == 0, 16-byte aligned images): the kernel the benchmark runs.
+//
+// Differences from the generic kernel above, each one answering a measurement (in-kernel s_memtime stamps, 64x64 tiles,
+// 4 workgroups per CU): phase B cost 8.3k cycles per tile and the loader's LDS-DMA issue 7.1k (~320 cycles per 1-KiB piece).
+//   * phase B works on 4 pixels per lane: a 16-lane DPP row holds one 64-pixel tile row, a wavefront sweeps 4 row blocks at
+//     once, taps come from ds_read_b128, the row scan is 3 serial adds + 4 DPP steps, column sums stay in registers;
+//   * the next tile is prefetched into registers by all 256 threads (5 x 16 B + <= 3 halo dwords each) right before the
+//     look-back polls are issued, and written to LDS at the top of the next iteration;
+//   * sub-segment totals T16 alias the (dead) raw tile, so LDS stays <= 37.3 KB per workgroup (4 workgroups per CU).
+// LDS image of a tile: raw[rows][72] dwords = [4 - O pad | O halo | 64 interior | O halo | pad], rows = 64 + 2 O.
+template<int O>
+__global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
+	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
+	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
+	constexpr int NI = (ROWS + 15) / 16;           // interior: 16 lanes x 16 B per row, 16 rows per pass
+	constexpr int NHAL = (ROWS * 2 * O + 255) / 256; // halo dwords per thread
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	uint32_t* raw = reinterpret_cast<uint32_t*>(smem);
+	int* T16 = reinterpret_cast<int*>(smem); // [16][64] column totals of the 4-row sub-segments; aliases raw (dead after phase B)
+	int* S = reinterpret_cast<int*>(raw + ROWS * PITCH);
+	int* Av = S + TH * TW;
+	int* Bv = Av + TW;
+	int* misc = Bv + TH; // [0] first ticket, [1] K, [2] Q, [3] next ticket
+
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int w = a.w, h = a.h;
+	const int perFrame = a.tilesX * a.tilesY;
+	const int f = (int)(blockIdx.x % (unsigned)a.batch);
+	uint32_t* queue = a.ctrl + 16 + 16 * f;
+	const size_t frame = (size_t)f * w * h;
+	const uint32_t* flat = in + frame;
+	int32_t* out = sat + frame;
+	const bool loader = tid == 3 * 64;
+	const bool abl_gran = a.debug & 64, abl_store = a.debug & 128, abl_load = a.debug & 256, abl_comp = a.debug & 512;
+
+	uint32_t pending = 0;
+	if(loader) {
+		const uint32_t t0 = atomicAdd(queue, 1u);
+		pending = atomicAdd(queue, 1u);
+		misc[0] = (int)(t0 - a.ticket_base);
+		misc[4] = (int)(__builtin_amdgcn_s_getreg(0x1804) & 3u); // HW_ID.wave_id: differs between workgroups sharing a SIMD
+	}
+	__syncthreads();
+	int rem = misc[0];
+	if(rem < 0 || rem >= perFrame) return;
+	if(a.debug & 1024) { // experiment: stagger co-resident workgroups so they do not convoy through the same phase together
+		const int slot = misc[4];
+		for(int i = 0; i < slot * (a.debug >> 12); i++) __builtin_amdgcn_s_sleep(16);
+	}
+
+	// ---- register image of the next tile -------------------------------------------------------------------------------
+	uint4 pv0, pv1, pv2, pv3, pv4;
+	uint32_t hv0 = 0, hv1 = 0, hv2 = 0;
+	const int c4 = tid & 15, r16 = tid >> 4;
+#define VP_PF_ROW(P) (min(r16 + 16 * (P), ROWS - 1))
+#define VP_PF_LOAD(P, X0, Y0) (*reinterpret_cast<const uint4*>(flat + (size_t)vp_clampi((Y0) - O + VP_PF_ROW(P), 0, h - 1) * w + (X0) + 4 * c4))
+#define VP_HALO_E(J) (min(tid + 256 * (J), ROWS * 2 * O - 1))
+#define VP_HALO_GX(J, X0) ((VP_HALO_E(J) % (2 * O)) < O ? (X0) - O + (VP_HALO_E(J) % (2 * O)) : (X0) + TW + (VP_HALO_E(J) % (2 * O)) - O)
+#define VP_HALO_LOAD(J, X0, Y0) (flat[(size_t)vp_clampi((Y0) - O + VP_HALO_E(J) / (2 * O), 0, h - 1) * w + vp_clampi(VP_HALO_GX(J, X0), 0, w - 1)])
+#define VP_PREFETCH(X0, Y0)                            \
+	do {                                                 \
+		pv0 = VP_PF_LOAD(0, X0, Y0);                     \
+		pv1 = VP_PF_LOAD(1, X0, Y0);                     \
+		pv2 = VP_PF_LOAD(2, X0, Y0);                     \
+		pv3 = VP_PF_LOAD(3, X0, Y0);                     \
+		if(NI > 4) pv4 = VP_PF_LOAD(4, X0, Y0);          \
+		hv0 = VP_HALO_LOAD(0, X0, Y0);                   \
+		if(NHAL > 1) hv1 = VP_HALO_LOAD(1, X0, Y0);      \
+		if(NHAL > 2) hv2 = VP_HALO_LOAD(2, X0, Y0);      \
+	} while(0)
+#define VP_COMMIT_ROW(P, V)                                                                                       \
+	do {                                                                                                            \
+		if(r16 + 16 * (P) < ROWS) *reinterpret_cast<uint4*>(raw + (r16 + 16 * (P)) * PITCH + 4 + 4 * c4) = (V);    \
+	} while(0)
+#define VP_COMMIT_HALO(J, V)                                                                                      \
+	do {                                                                                                            \
+		const int e_ = tid + 256 * (J);                                                                             \
+		if(e_ < ROWS * 2 * O) {                                                                                     \
+			const int k_ = e_ % (2 * O);                                                                            \
+			raw[(e_ / (2 * O)) * PITCH + (k_ < O ? 4 - O + k_ : 4 + TW + (k_ - O))] = (V);                          \
+		}                                                                                                           \
+	} while(0)
+	pv4 = make_uint4(0, 0, 0, 0);
+	{
+		const uint32_t t0 = a.order[__builtin_amdgcn_readfirstlane(rem)]; // scalar load: off the congested vector-memory path
+		VP_PREFETCH((int)(t0 & 0xFFFF) * TW, (int)(t0 >> 16) * TH);
+	}
+
+	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const bool stamp = (a.debug & 8) && lane == 0 && (wv == 0 || wv == 3);
+	for(;;) {
+		const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		const uint32_t tcur = a.order[__builtin_amdgcn_readfirstlane(rem)];
+		const int ti = (int)(tcur >> 16), tj = (int)(tcur & 0xFFFF);
+		const int x0 = tj * TW, y0 = ti * TH;
+
+		// ---- A: registers -> LDS; publish the next ticket, request the one after --------------------------------------
+		VP_COMMIT_ROW(0, pv0);
+		VP_COMMIT_ROW(1, pv1);
+		VP_COMMIT_ROW(2, pv2);
+		VP_COMMIT_ROW(3, pv3);
+		if(NI > 4) VP_COMMIT_ROW(4, pv4);
+		VP_COMMIT_HALO(0, hv0);
+		if(NHAL > 1) VP_COMMIT_HALO(1, hv1);
+		if(NHAL > 2) VP_COMMIT_HALO(2, hv2);
+		if(loader) misc[3] = (int)(pending - a.ticket_base);
+		lds_barrier();
+		const unsigned long long ts1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		if(loader) pending = atomicAdd(queue, 1u);
+		const int next = misc[3];
+		const bool more = next >= 0 && next < perFrame;
+
+		// early polls: the carries of the two nearest predecessors of each chain, requested before our own sums exist
+		const size_t tile = (size_t)f * perFrame + (size_t)ti * a.tilesX + tj;
+		u64 pre0 = 0, pre1 = 0;
+		if(abl_gran) {
+		} else if(wv == 0 && ti > 0) {
+			const u64* g = a.V + tile * TW + lane;
+			pre0 = ld_granule(g - (long)a.tilesX * TW);
+			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX * TW);
+		} else if(wv == 1 && tj > 0) {
+			const u64* g = a.H + tile * TH + lane;
+			pre0 = ld_granule(g - TH);
+			if(tj > 1) pre1 = ld_granule(g - 2 * TH);
+		} else if(wv == 2 && ti > 0) {
+			const u64* g = a.K + tile;
+			pre0 = ld_granule(g - a.tilesX);
+			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX);
+		}
+
+		// ---- B: 4 pixels per lane; lane = 16 q + m: columns 4m..4m+3, rows 16 wv + 4 q + it ---------------------------
+		const int m = lane & 15, q = lane >> 4;
+		int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
+#pragma unroll 2
+		for(int it = 0; it < (abl_comp ? 0 : 4); it++) {
+			const int r = 16 * wv + 4 * q + it;
+			const uint32_t* c = raw + (r + O) * PITCH + 4 + 4 * m;
+			const uint4 L = *reinterpret_cast<const uint4*>(c - 4), C = *reinterpret_cast<const uint4*>(c), R = *reinterpret_cast<const uint4*>(c + 4);
+			const uint4 U = *reinterpret_cast<const uint4*>(c - O * PITCH), D = *reinterpret_cast<const uint4*>(c + O * PITCH);
+			const uint32_t hx[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
+			int g0 = grad_dot_pk(hx[4 + O], hx[4 - O], D.x, U.x);
+			int g1 = grad_dot_pk(hx[5 + O], hx[5 - O], D.y, U.y);
+			int g2 = grad_dot_pk(hx[6 + O], hx[6 - O], D.z, U.z);
+			int g3 = grad_dot_pk(hx[7 + O], hx[7 - O], D.w, U.w);
+			const bool yin = y0 + r < h;
+			if(!yin) g0 = g1 = g2 = g3 = 0;
+			if(gd_out && yin) *reinterpret_cast<float4*>(gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
+			g1 += g0;
+			g2 += g1;
+			g3 += g2;
+			int s = g3; // inclusive scan of the lane totals over the 16 lanes of this row
+			s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);
+			s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);
+			s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);
+			s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);
+			const int ex = s - g3;
+			run0 += g0 + ex;
+			run1 += g1 + ex;
+			run2 += g2 + ex;
+			run3 += g3 + ex;
+			*reinterpret_cast<int4*>(S + r * TW + 4 * m) = make_int4(run0, run1, run2, run3);
+		}
+		const unsigned long long tsb1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		lds_barrier(); // every wave is done with raw
+		const unsigned long long tsb2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		*reinterpret_cast<int4*>(T16 + (4 * wv + q) * TW + 4 * m) = make_int4(run0, run1, run2, run3);
+		const unsigned long long tsb3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		lds_barrier();
+		const unsigned long long ts2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+
+		// ---- C/D: aggregates, publication, look-back -------------------------------------------------------------------
+		if(wv == 0) { // column chain: A(x)
+			int pc = 0;
+#pragma unroll
+			for(int sg = 0; sg < 16; sg++) pc += T16[sg * TW + lane]; // bottom row of the local SAT
+			u64* g = a.V + tile * TW + lane;
+			int carry = 0;
+			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) {
+				st_granule(g, a.epoch, ST_AGG, pc);
+				lookback(g, (long)a.tilesX * TW, ti, a, carry);
+			}
+			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pc);
+			Av[lane] = carry;
+		} else if(wv == 1) { // row chain: B(y), then the corner chain's aggregate Q = B(TH-1)
+			int pr = S[lane * TW + TW - 1]; // right column of the local SAT
+			for(int sg = 0; sg < (lane >> 2); sg++) pr += T16[sg * TW + TW - 1];
+			u64* g = a.H + tile * TH + lane;
+			int carry = 0;
+			if(!abl_gran && tj > 0 && !early_resolve(pre0, pre1, tj, a, carry)) {
+				st_granule(g, a.epoch, ST_AGG, pr);
+				lookback(g, TH, tj, a, carry);
+			}
+			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pr);
+			Bv[lane] = carry;
+			if(lane == TH - 1) {
+				misc[2] = carry;
+				if(!abl_gran) st_granule(a.K + tile, a.epoch, ti > 0 ? ST_AGG : ST_INC, carry);
+			}
+		} else if(wv == 2) { // corner chain
+			int carry = 0;
+			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback(a.K + tile, a.tilesX, ti, a, carry);
+			if(lane == 0) misc[1] = carry;
+		}
+		const unsigned long long ts3a = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		lds_barrier();
+		const unsigned long long ts3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+		const int K = misc[1];
+		if(!abl_gran && wv == 1 && lane == 0 && ti > 0) st_granule(a.K + tile, a.epoch, ST_INC, K + misc[2]);
+		// next tile -> registers: in flight across phase E and the loop barrier, consumed at the next phase A
+		if(more && !abl_load) {
+			const uint32_t tn = a.order[__builtin_amdgcn_readfirstlane(next)];
+			VP_PREFETCH((int)(tn & 0xFFFF) * TW, (int)(tn >> 16) * TH);
+		}
+
+		// ---- E: out = local + (sub-segment totals above) + A(x) + B(y) + K ------------------------------------------------
+		{
+			const int cg = tid & 15, rr = tid >> 4;
+			const int4 av = *reinterpret_cast<const int4*>(Av + 4 * cg);
+			int4 add = make_int4(av.x + K, av.y + K, av.z + K, av.w + K);
+			int sgdone = 0; // sub-segments already folded into `add`
+			const int gx = x0 + 4 * cg;
+#pragma unroll
+			for(int k = 0; k < 4; k++) {
+				const int r = rr + 16 * k, gy = y0 + r;
+				const int sgneed = r >> 2;
+				for(; sgdone < sgneed; sgdone++) {
+					const int4 t = *reinterpret_cast<const int4*>(T16 + sgdone * TW + 4 * cg);
+					add = make_int4(add.x + t.x, add.y + t.y, add.z + t.z, add.w + t.w);
+				}
+				const int4 sv = *reinterpret_cast<const int4*>(S + r * TW + 4 * cg);
+				const int b = Bv[r];
+				if(gy < h && !abl_store) *reinterpret_cast<int4*>(out + (size_t)gy * w + gx) = make_int4(sv.x + add.x + b, sv.y + add.y + b, sv.z + add.z + b, sv.w + add.w + b);
+			}
+		}
+		if(stamp) {
+			const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+			ph[0] += ts1 - ts0; ph[1] += ts2 - ts1; ph[2] += ts3a - ts2; ph[3] += ts3 - ts3a; ph[4] += ts4 - ts3;
+			ph[5] += tsb1 - ts1; ph[6] += tsb2 - tsb1; ph[7] += tsb3 - tsb2;
+		}
+		if(!more) break;
+		rem = next;
+		lds_barrier(); // T16 (aliasing raw), S, Av, Bv, misc of this tile are dead only now
+	}
+	if(stamp) {
+		unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.ctrl + 16 + 16 * a.batch) + (wv == 3 ? 8 : 0);
+		for(int k = 0; k < 8; k++) atomicAdd(acc + k, ph[k]);
+	}
+#undef VP_PF_ROW
+#undef VP_PF_LOAD
+#undef VP_HALO_E
+#undef VP_HALO_GX
+#undef VP_HALO_LOAD
+#undef VP_PREFETCH
+#undef VP_COMMIT_ROW
+#undef VP_COMMIT_HALO
 }
 
 } // namespace
@@ -387,7 +673,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	const size_t lds = sizeof(int) * ((size_t)((rawRows + 3) & ~3) * TW + a.pitch + TH * TW + NWAVES * TW + TW + TH + 8);
 
 	// persistent carry state (slot 1): [control: abort word + one 64-B ticket line per frame][V][H][K]
-	const size_t bCtl = 64 * ((size_t)batch + 1);
+	const size_t bCtl = 64 * ((size_t)batch + 1) + 128; // + debug phase accumulators
 	const size_t bOrd = (sizeof(uint32_t) * (size_t)a.tilesX * a.tilesY + 255) & ~size_t(255);
 	const size_t bV = sizeof(u64) * (size_t)a.nTiles * TW, bH = sizeof(u64) * (size_t)a.nTiles * TH, bK = sizeof(u64) * (size_t)a.nTiles;
 	void* base = nullptr;
@@ -466,6 +752,16 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	ctx->sat_ticket_base[stream] += (uint32_t)(perFrame + 2 * P);
 	const unsigned grid = (unsigned)P * (unsigned)batch;
 	const bool pipe = fused && o >= 1 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !(a.debug & 2);
+	const bool fast = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
+			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0) && !(a.debug & 16);
+	if(fast) {
+		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8);
+		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
+		if(o == 1) k_sat_fast<1><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
+		else if(o == 2) k_sat_fast<2><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
+		else if(o == 3) k_sat_fast<3><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
+		else k_sat_fast<4><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
+	} else {
 #define VP_TILED_LAUNCH(M) \
 	do { \
 		if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sat_tiled<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -475,6 +771,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	else if(!pipe) VP_TILED_LAUNCH(-1);
 	else VP_TILED_LAUNCH(1);
 #undef VP_TILED_LAUNCH
+	}
 	VP_TRY(vp_launch_ok("tiled sat"));
 	if(a.debug & 4) { // look-back statistics (debug only): windows, re-polls, chains, predecessors visited
 		uint32_t st[4];
@@ -482,6 +779,16 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 		VP_CHECK_HIP(hipMemcpy(st, a.ctrl + 8, sizeof(st), hipMemcpyDeviceToHost));
 		fprintf(stderr, "[sat-debug] chains %u windows %u repolls %u predecessors %u\n", st[2], st[0], st[1], st[3]);
 		VP_CHECK_HIP(hipMemset(a.ctrl + 8, 0, sizeof(st)));
+	}
+	if(a.debug & 8) { // in-kernel phase stamps (debug only; shader cycles summed over workgroups, wave 0 then wave 3)
+		unsigned long long acc[16];
+		VP_CHECK_HIP(hipStreamSynchronize(s));
+		VP_CHECK_HIP(hipMemcpy(acc, a.ctrl + 16 + 16 * batch, sizeof(acc), hipMemcpyDeviceToHost));
+		const double n = (double)a.nTiles;
+		fprintf(stderr, "[sat-phase] cycles/tile wave0: A(wait tile) %.0f  B %.0f  C/D(look-back) %.0f  barrier %.0f  E %.0f | wave3: A %.0f  B %.0f  C/D(dma issue) %.0f  barrier %.0f  E %.0f\n",
+				acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[8] / n, acc[9] / n, acc[10] / n, acc[11] / n, acc[12] / n);
+		fprintf(stderr, "[sat-phase] fast kernel split of B, wave0: compute %.0f  barrier %.0f  T16+prefetch issue %.0f | wave3: %.0f %.0f %.0f\n", acc[5] / n, acc[6] / n, acc[7] / n, acc[13] / n, acc[14] / n, acc[15] / n);
+		VP_CHECK_HIP(hipMemset(a.ctrl + 16 + 16 * batch, 0, sizeof(acc)));
 	}
 	return VP_OK;
 }
