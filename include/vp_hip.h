@@ -119,6 +119,16 @@ int vp_resample(VpContext* ctx, int stream, const uint8_t* planes, int layout, i
 int vp_resample_raw(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const VpCameraModel* model,
 		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat);
 
+/* Coordinate map: field2image() of every flat pixel (resampling.cl:29-47 evaluated at :53).  It depends on the geometry only
+ * (Perspective::geometryCheck runs once per geometry version, Perspective.cpp:37-38), not on the frame, so the 18 IEEE
+ * divisions per pixel can be paid once.  map: fh x fw pairs (px, py) of binary32 quad-plane coordinates. */
+int vp_resample_map(VpContext* ctx, int stream, const VpCameraModel* model, float max_robot_height, float field_scale, float off_x, float off_y,
+		int fw, int fh, float* map);
+
+/* vp_resample_raw with the coordinates read from a map built by vp_resample_map for the same geometry: identical output. */
+int vp_resample_raw_mapped(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const float* map, int sampler_mode,
+		int fw, int fh, int batch, uint8_t* flat);
+
 /* gradient_dotproduct (gradientDot.cl:22-30; Resources.cpp:160).  graddot: batch x h x w float (exact integers). */
 int vp_graddot(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, float* graddot);
 
@@ -166,6 +176,7 @@ typedef struct {
 	float min_score;                   /* 0.0f at the reference call site          (main.cpp:289) */
 	int32_t max_matches;               /* maxBlobs */
 	int32_t sampler_mode, sat_variant, order;
+	int32_t use_coord_map;             /* 1: vp_frame keeps a per-stream coordinate map (rebuilt when the geometry scalars change) */
 } VpFrameParams;
 
 typedef struct {

@@ -86,6 +86,11 @@ def test_golden_chain_stage_by_stage(gpu, cfg, mode, seed):
     d_flat2 = torch.zeros_like(d_flat)
     ctx.resample_raw(d_raw, layout, qw, qh, model, mrh, fs, ox, oy, smode, fw, fh, 1, d_flat2)
     assert np.array_equal(host(d_flat2), g["flat"]), "fused raw2quad+resampling"
+    d_map = torch.zeros((fh, fw, 2), dtype=torch.float32, device="cuda")
+    ctx.resample_map(model, mrh, fs, ox, oy, fw, fh, d_map)
+    d_flat3 = torch.zeros_like(d_flat)
+    ctx.resample_raw_mapped(d_raw, layout, qw, qh, d_map, smode, fw, fh, 1, d_flat3)
+    assert np.array_equal(host(d_flat3), g["flat"]), "coordinate-map resampling"
 
     d_flat = dev(torch, g["flat"])
     d_gd = torch.zeros((fh, fw), dtype=torch.float32, device="cuda")
@@ -128,7 +133,7 @@ def test_golden_chain_stage_by_stage(gpu, cfg, mode, seed):
 def test_golden_whole_frame(gpu, cfg, mode, seed, variant):
     capi, ctx, torch = gpu
     g = cases.load_golden(cases.chain_case_name(cfg, mode, seed))
-    p = capi.frame_params(cfg, sat_variant=variant[1], order=capi.ORDER_RASTER, sampler_mode=mode)
+    p = capi.frame_params(cfg, sat_variant=variant[1], order=capi.ORDER_RASTER, sampler_mode=mode, use_coord_map=(seed + mode) % 2 == 0)
     mm = cfg.max_matches
     d = dict(flat=torch.zeros((cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
              matches=torch.zeros(mm * 22, dtype=torch.uint8, device="cuda"), idx=torch.zeros(mm, dtype=torch.int32, device="cuda"),

@@ -29,7 +29,7 @@ class VpFrameParams(C.Structure):
         ("max_robot_height", C.c_float), ("field_scale", C.c_float), ("off_x", C.c_float), ("off_y", C.c_float),
         ("fw", C.c_int32), ("fh", C.c_int32), ("grad_offset", C.c_int32), ("circle_radius", C.c_int32), ("list_radius", C.c_int32),
         ("circ_threshold", C.c_float), ("min_score", C.c_float), ("max_matches", C.c_int32),
-        ("sampler_mode", C.c_int32), ("sat_variant", C.c_int32), ("order", C.c_int32),
+        ("sampler_mode", C.c_int32), ("sat_variant", C.c_int32), ("order", C.c_int32), ("use_coord_map", C.c_int32),
     ]
 
 
@@ -79,7 +79,7 @@ def _ptr(x):
     raise TypeError(type(x))
 
 
-def frame_params(cfg, sat_variant=SAT_TILED, order=ORDER_RASTER, sampler_mode=None) -> VpFrameParams:
+def frame_params(cfg, sat_variant=SAT_TILED, order=ORDER_RASTER, sampler_mode=None, use_coord_map=True) -> VpFrameParams:
     p = VpFrameParams()
     p.layout, p.qw, p.qh = cfg.layout, cfg.qw, cfg.qh
     p.model = cfg.model()
@@ -89,6 +89,7 @@ def frame_params(cfg, sat_variant=SAT_TILED, order=ORDER_RASTER, sampler_mode=No
     p.circ_threshold, p.min_score, p.max_matches = cfg.circ_threshold, cfg.min_score, cfg.max_matches
     p.sampler_mode = cfg.sampler_mode if sampler_mode is None else sampler_mode
     p.sat_variant, p.order = sat_variant, order
+    p.use_coord_map = int(use_coord_map)
     return p
 
 
@@ -178,6 +179,12 @@ class Context:
 
     def resample_raw(self, raw, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream=0):
         self._resample(self.l.vp_resample_raw, raw, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream)
+
+    def resample_map(self, model, height, fs, ox, oy, fw, fh, map_out, stream=0):
+        self._ck(self.l.vp_resample_map(self.h, stream, C.byref(model), C.c_float(height), C.c_float(fs), C.c_float(ox), C.c_float(oy), int(fw), int(fh), _ptr(map_out)))
+
+    def resample_raw_mapped(self, raw, layout, qw, qh, map_in, mode, fw, fh, batch, flat, stream=0):
+        self._ck(self.l.vp_resample_raw_mapped(self.h, stream, _ptr(raw), int(layout), int(qw), int(qh), _ptr(map_in), int(mode), int(fw), int(fh), int(batch), _ptr(flat)))
 
     def graddot(self, flat, w, h, offset, batch, out, stream=0):
         self._ck(self.l.vp_graddot(self.h, stream, _ptr(flat), int(w), int(h), int(offset), int(batch), _ptr(out)))

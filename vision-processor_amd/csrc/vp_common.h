@@ -29,7 +29,8 @@ struct VpContext {
 	int n_streams = 0;
 	bool own_streams = true;
 	hipStream_t streams[VP_MAX_STREAMS] = {};
-	VpWorkspace ws[2][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries
+	VpWorkspace ws[3][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries; slot 2: coordinate map
+	unsigned char map_key[VP_MAX_STREAMS][96] = {}; // geometry the cached coordinate map of each stream was built for
 	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // generation tag of the single-pass SAT carry granules
 	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tickets handed out per frame queue by all earlier launches on this stream (mod 2^32)
 	uint64_t sat_shape[VP_MAX_STREAMS] = {};       // tiling + batch those counters were advanced with

@@ -5,6 +5,8 @@
 // quad planes, gradDot and blobCenter are only written when the caller asks for them as debug / stream views.
 #include "vp_common.h"
 
+#include <cstring>
+
 extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(p && raw && b, "vp_frame: null pointer");
@@ -12,6 +14,22 @@ extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, cons
 	if(b->planes) {
 		VP_TRY(vp_raw2quad(ctx, stream, raw, p->layout, p->qw, p->qh, batch, b->planes));
 		VP_TRY(vp_resample(ctx, stream, b->planes, p->layout, p->qw, p->qh, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->sampler_mode, p->fw, p->fh, batch, b->flat));
+	} else if(p->use_coord_map) {
+		// the geometry changes once per calibration, not per frame: keep field2image() of every flat pixel in a per-stream map
+		unsigned char key[96] = {0};
+		memcpy(key, &p->model, sizeof(p->model));
+		const float sc[4] = {p->max_robot_height, p->field_scale, p->off_x, p->off_y};
+		memcpy(key + 72, sc, sizeof(sc));
+		const int32_t sz[2] = {p->fw, p->fh};
+		memcpy(key + 88, sz, sizeof(sz));
+		void* map = nullptr;
+		bool grew = false;
+		VP_TRY(vp_workspace(ctx, stream, 2, sizeof(float) * 2 * (size_t)p->fw * p->fh, &map, &grew));
+		if(grew || memcmp(key, ctx->map_key[stream], sizeof(key)) != 0) {
+			VP_TRY(vp_resample_map(ctx, stream, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->fw, p->fh, static_cast<float*>(map)));
+			memcpy(ctx->map_key[stream], key, sizeof(key));
+		}
+		VP_TRY(vp_resample_raw_mapped(ctx, stream, raw, p->layout, p->qw, p->qh, static_cast<const float*>(map), p->sampler_mode, p->fw, p->fh, batch, b->flat));
 	} else {
 		VP_TRY(vp_resample_raw(ctx, stream, raw, p->layout, p->qw, p->qh, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->sampler_mode, p->fw, p->fh, batch, b->flat));
 	}

@@ -128,6 +128,54 @@ __device__ __forceinline__ uint32_t sample(const uint8_t* __restrict__ src, int 
 	return (uint32_t)t;
 }
 
+// ---- Bayer fast sampling: 4 window loads instead of 16 byte gathers -------------------------------------------------------
+// The four positional channels of a 2x2 Bayer cell are sampled at (u +- 0.25, v +- 0.25) (resampling.cl:64-79).  Every texel the
+// four bilinear footprints touch lies in 4 raw rows (two even, two odd) and, horizontally, within 4 consecutive cells = 8
+// bytes.  One unaligned 8-byte load per row replaces 16 single-byte gathers; the arithmetic on the texel values is unchanged.
+typedef uint2 __attribute__((aligned(2))) uint2_a2;
+
+struct Axis { // spec 8.2 linear filter along one axis: clamped indices and weight
+	int i0, i1;
+	float a;
+};
+__device__ __forceinline__ Axis axis_lin(float u, int n) {
+	const float um = u - 0.5f, fu = floorf(um);
+	Axis r;
+	r.a = um - fu;
+	r.i0 = vp_clampi((int)fu, 0, n - 1);
+	r.i1 = vp_clampi((int)fu + 1, 0, n - 1);
+	return r;
+}
+__device__ __forceinline__ float win_byte(uint2 w, int k) { // byte k (0..7) of the 8-byte window
+	const unsigned long long v = ((unsigned long long)w.y << 32) | w.x;
+	return (float)(uint32_t)((v >> (8 * k)) & 0xFF);
+}
+// same evaluation order as sample<>(): w00*t00 + w10*t10 + w01*t01 + w11*t11, truncated
+__device__ __forceinline__ uint32_t bilin(float t00, float t10, float t01, float t11, float a, float b) {
+	const float oma = 1.0f - a, omb = 1.0f - b;
+	const float w00 = oma * omb, w10 = a * omb, w01 = oma * b, w11 = a * b;
+	float t = w00 * t00;
+	t = t + w10 * t10;
+	t = t + w01 * t01;
+	t = t + w11 * t11;
+	return (uint32_t)t;
+}
+// p[0..3]: positional channels (even row/even col, even/odd, odd/even, odd/odd) sampled with BILINEAR_RTZ
+__device__ __forceinline__ void sample_bayer4(const uint8_t* __restrict__ raw, float px, float py, int qw, int qh, uint32_t p[4]) {
+	const Axis xa = axis_lin(px + 0.25f, qw), xb = axis_lin(px - 0.25f, qw);
+	const Axis ya = axis_lin(py + 0.25f, qh), yb = axis_lin(py - 0.25f, qh);
+	const int ibase = vp_clampi(min(xa.i0, xb.i0), 0, qw - 4);
+	const size_t row = 2 * (size_t)qw;
+	const uint8_t* base = raw + 2 * (size_t)ibase;
+	const uint2 e0 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * ya.i0) * row), e1 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * ya.i1) * row);
+	const uint2 o0 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * yb.i0 + 1) * row), o1 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * yb.i1 + 1) * row);
+	const int a0 = 2 * (xa.i0 - ibase), a1 = 2 * (xa.i1 - ibase), b0 = 2 * (xb.i0 - ibase) + 1, b1 = 2 * (xb.i1 - ibase) + 1;
+	p[0] = bilin(win_byte(e0, a0), win_byte(e0, a1), win_byte(e1, a0), win_byte(e1, a1), xa.a, ya.a);
+	p[1] = bilin(win_byte(e0, b0), win_byte(e0, b1), win_byte(e1, b0), win_byte(e1, b1), xb.a, ya.a);
+	p[2] = bilin(win_byte(o0, a0), win_byte(o0, a1), win_byte(o1, a0), win_byte(o1, a1), xa.a, yb.a);
+	p[3] = bilin(win_byte(o0, b0), win_byte(o0, b1), win_byte(o1, b0), win_byte(o1, b1), xb.a, yb.a);
+}
+
 template<int LAYOUT, int MODE, bool FROM_RAW>
 __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ src, uint8_t* __restrict__ flat, const ResampleArgs a, size_t src_frame_bytes) {
 	const int gx = blockIdx.x * 64 + threadIdx.x;
@@ -141,6 +189,11 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 		r = sample<LAYOUT, MODE, FROM_RAW>(s, 2, px, py, a.qw, a.qh);
 		g = sample<LAYOUT, MODE, FROM_RAW>(s, 1, px, py, a.qw, a.qh);
 		b = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px, py, a.qw, a.qh);
+	} else if(FROM_RAW && MODE == VP_SAMPLER_BILINEAR_RTZ && a.qw >= 4) {
+		uint32_t p[4];
+		sample_bayer4(s, px, py, a.qw, a.qh, p);
+		if(LAYOUT == VP_LAYOUT_RGGB) { r = p[0]; g = p[1] / 2 + p[2] / 2; b = p[3]; }
+		else { r = p[1]; g = p[0] / 2 + p[3] / 2; b = p[2]; }
 	} else if(LAYOUT == VP_LAYOUT_RGGB) { // :64-71
 		r = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px + 0.25f, py + 0.25f, a.qw, a.qh);
 		g = sample<LAYOUT, MODE, FROM_RAW>(s, 1, px - 0.25f, py + 0.25f, a.qw, a.qh) / 2 + sample<LAYOUT, MODE, FROM_RAW>(s, 2, px + 0.25f, py - 0.25f, a.qw, a.qh) / 2;
@@ -154,6 +207,94 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
 	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
 	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * a.fw * a.fh + (size_t)gy * a.fw + gx] = px4;
+}
+
+// ---- coordinate map ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resample_map(float2* __restrict__ map, const ResampleArgs a) {
+	const int gx = blockIdx.x * 64 + threadIdx.x;
+	const int gy = blockIdx.y * 4 + threadIdx.y;
+	if(gx >= a.fw || gy >= a.fh) return;
+	float px, py;
+	field2image(a.m, (float)gx * a.fs + a.ox, (float)gy * a.fs + a.oy, a.height, px, py);
+	map[(size_t)gy * a.fw + gx] = make_float2(px, py);
+}
+
+template<int LAYOUT, int MODE>
+__global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
+		int qw, int qh, int fw, int fh, size_t src_frame_bytes) {
+	const int gx = blockIdx.x * 64 + threadIdx.x;
+	const int gy = blockIdx.y * 4 + threadIdx.y;
+	if(gx >= fw || gy >= fh) return;
+	const float2 pos = map[(size_t)gy * fw + gx];
+	const float px = pos.x, py = pos.y;
+	const uint8_t* s = raw + (size_t)blockIdx.z * src_frame_bytes;
+	uint32_t r, g, b;
+	if(LAYOUT == VP_LAYOUT_BGR) {
+		r = sample<LAYOUT, MODE, true>(s, 2, px, py, qw, qh);
+		g = sample<LAYOUT, MODE, true>(s, 1, px, py, qw, qh);
+		b = sample<LAYOUT, MODE, true>(s, 0, px, py, qw, qh);
+	} else if(MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
+		uint32_t p[4];
+		sample_bayer4(s, px, py, qw, qh, p);
+		if(LAYOUT == VP_LAYOUT_RGGB) { r = p[0]; g = p[1] / 2 + p[2] / 2; b = p[3]; }
+		else { r = p[1]; g = p[0] / 2 + p[3] / 2; b = p[2]; }
+	} else if(LAYOUT == VP_LAYOUT_RGGB) {
+		r = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh);
+		g = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh) / 2;
+		b = sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh);
+	} else {
+		r = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh);
+		g = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh) / 2;
+		b = sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh);
+	}
+	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
+	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
+	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * fw * fh + (size_t)gy * fw + gx] = px4;
+}
+
+extern "C" int vp_resample_map(VpContext* ctx, int stream, const VpCameraModel* model, float max_robot_height, float field_scale, float off_x, float off_y,
+		int fw, int fh, float* map) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(model && map && fw > 0 && fh > 0 && (reinterpret_cast<uintptr_t>(map) & 7) == 0, "vp_resample_map: bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "resampling map");
+	ResampleArgs a;
+	a.m = *model;
+	a.height = max_robot_height;
+	a.fs = field_scale;
+	a.ox = off_x;
+	a.oy = off_y;
+	a.qw = a.qh = 0;
+	a.fw = fw;
+	a.fh = fh;
+	k_resample_map<<<dim3(vp_div_up(fw, 64), vp_div_up(fh, 4)), dim3(64, 4), 0, ctx->streams[stream]>>>(reinterpret_cast<float2*>(map), a);
+	return vp_launch_ok("resampling map");
+}
+
+extern "C" int vp_resample_raw_mapped(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const float* map, int sampler_mode,
+		int fw, int fh, int batch, uint8_t* flat) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(raw && map && flat && qw > 0 && qh > 0 && fw > 0 && fh > 0 && batch > 0 && batch <= 65535, "vp_resample_raw_mapped: bad arguments");
+	VP_REQUIRE(layout >= 0 && layout <= 2 && (sampler_mode == VP_SAMPLER_NEAREST || sampler_mode == VP_SAMPLER_BILINEAR_RTZ), "vp_resample_raw_mapped: bad layout/sampler mode");
+	VP_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 3) == 0 && (reinterpret_cast<uintptr_t>(map) & 7) == 0, "vp_resample_raw_mapped: misaligned buffer");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "raw2quad+resampling");
+	const size_t q = (size_t)qw * qh, frame_bytes = layout == VP_LAYOUT_BGR ? 3 * q : 4 * q;
+	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), batch), block(64, 4);
+	hipStream_t s = ctx->streams[stream];
+	const float2* m2 = reinterpret_cast<const float2*>(map);
+#define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes)
+	if(sampler_mode == VP_SAMPLER_NEAREST) {
+		if(layout == VP_LAYOUT_RGGB) VP_RM(VP_LAYOUT_RGGB, VP_SAMPLER_NEAREST);
+		else if(layout == VP_LAYOUT_GRBG) VP_RM(VP_LAYOUT_GRBG, VP_SAMPLER_NEAREST);
+		else VP_RM(VP_LAYOUT_BGR, VP_SAMPLER_NEAREST);
+	} else {
+		if(layout == VP_LAYOUT_RGGB) VP_RM(VP_LAYOUT_RGGB, VP_SAMPLER_BILINEAR_RTZ);
+		else if(layout == VP_LAYOUT_GRBG) VP_RM(VP_LAYOUT_GRBG, VP_SAMPLER_BILINEAR_RTZ);
+		else VP_RM(VP_LAYOUT_BGR, VP_SAMPLER_BILINEAR_RTZ);
+	}
+#undef VP_RM
+	return vp_launch_ok("raw2quad+resampling (mapped)");
 }
 
 template<bool FROM_RAW>

@@ -147,20 +147,32 @@ __device__ __forceinline__ float disc_score_wave(const uint32_t* __restrict__ f,
 	return circ / (sd[0] + sd[1] + sd[2]);       // :78
 }
 
-// blobList.cl:57-102, one wavefront per candidate
-__global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat, const float* __restrict__ circ, const uint32_t* __restrict__ cand,
+// blobList.cl:57-102, one wavefront per candidate.  FROM_SAT: blobCenter was never materialised; the five values the record
+// needs (centre + 4 neighbours, clamp-to-edge) are recomputed from the SAT by lanes 0-4.
+template<bool FROM_SAT>
+__global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat, const void* __restrict__ src, const uint32_t* __restrict__ cand,
 		const int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, uint8_t* __restrict__ matches, uint32_t* __restrict__ idx_out,
-		int w, int h, float min_score, int radius, int max_matches) {
+		int w, int h, float min_score, int radius, int max_matches, int circle_radius) {
 	const int z = blockIdx.y;
 	const size_t n = (size_t)w * h;
 	const uint32_t* f = flat + z * n;
-	const float* c = circ + z * n;
+	const float* c = reinterpret_cast<const float*>(src) + z * n;
+	const int32_t* sat = reinterpret_cast<const int32_t*>(src) + z * n;
 	const int lane = threadIdx.x & 63;
 	const int total = cand_count[z];
 	for(int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < total; k += gridDim.x * 4) {
 		const uint32_t pix = cand[z * n + k];
 		const int px = (int)(pix % (uint32_t)w), py = (int)(pix / (uint32_t)w);
-		const float v = c[pix];
+		float v, nx, qx, ny, qy;
+		if(FROM_SAT) {
+			const int dx = lane == 1 ? -1 : (lane == 2 ? 1 : 0), dy = lane == 3 ? -1 : (lane == 4 ? 1 : 0);
+			const float mine = lane < 5 ? circle_at(sat, w, h, vp_clampi(px + dx, 0, w - 1), vp_clampi(py + dy, 0, h - 1), circle_radius, (float)(circle_radius * circle_radius)) : 0.f;
+			v = __shfl(mine, 0, 64); nx = __shfl(mine, 1, 64); qx = __shfl(mine, 2, 64); ny = __shfl(mine, 3, 64); qy = __shfl(mine, 4, 64);
+		} else {
+			v = c[pix];
+			nx = bc_tap(c, w, h, px - 1, py); qx = bc_tap(c, w, h, px + 1, py);
+			ny = bc_tap(c, w, h, px, py - 1); qy = bc_tap(c, w, h, px, py + 1);
+		}
 		uint32_t color[3];
 		const float score = disc_score_wave(f, w, h, px, py, radius, v, color);
 		if(lane != 0) continue;
@@ -170,8 +182,6 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 		}
 		const int i = atomicAdd(&counter[3 * z], 1); // :87
 		if(i >= max_matches) continue;               // :88-89
-		const float nx = bc_tap(c, w, h, px - 1, py), qx = bc_tap(c, w, h, px + 1, py);
-		const float ny = bc_tap(c, w, h, px, py - 1), qy = bc_tap(c, w, h, px, py + 1);
 		const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
 		const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
 		store_match(matches + ((size_t)z * max_matches + i) * 22, mx, my, color, f[pix], v, score);
@@ -219,16 +229,85 @@ __global__ __launch_bounds__(256) void k_copy_back(const uint8_t* __restrict__ r
 	if(idx) idx[(size_t)z * max_matches + t] = idx_tmp[(size_t)z * max_matches + t];
 }
 
-static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch, float thr, float min_score,
-		int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, const ListScratch& ws) {
+// circle + detect fused: the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge addressing (satBlobCenter.cl:20, H7),
+// blobCenter is computed for the 64x32 tile plus a 1-pixel ring into LDS, then thresholded / peak-tested (blobList.cl:37-55).
+// Out-of-image ring positions take the value of the clamped position, exactly what the clamped reads of the reference return.
+constexpr int FT_W = 64, FT_H = 32;
+
+__global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
+		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r, float thr) {
+	extern __shared__ __attribute__((aligned(16))) char smem_tail[];
+	const int halo = r + 1;
+	const int RW = FT_W + 2 * halo, RH = FT_H + 2 * halo;
+	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - halo + rx)]
+	float* bc = reinterpret_cast<float*>(region + RW * RH);   // (FT_H + 2) x (FT_W + 2)
+	const int z = blockIdx.z;
+	const size_t n = (size_t)w * h;
+	const int32_t* sat = sat_all + z * n;
+	const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+	const int tid = threadIdx.x;
+	for(int ry = tid >> 6; ry < RH; ry += 4) {
+		const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
+		for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - halo + rx, 0, w - 1)];
+	}
+	__syncthreads();
+	const float div = (float)(r * r);
+	constexpr int BW = FT_W + 2, BH = FT_H + 2;
+	for(int e = tid; e < BW * BH; e += 256) {
+		const int by = e / BW, bx = e - by * BW;
+		// centre in image coordinates, clamped; region coordinates of the centre
+		const int cx = vp_clampi(x0 - 1 + bx, 0, w - 1) - (x0 - halo), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - halo);
+		const uint32_t* c = region + cy * RW + cx;
+#define RG(DX, DY) c[(DY) * RW + (DX)]
+		const float pp = (float)(int32_t)(RG(r, r) - RG(r, 1) - RG(1, r) + RG(1, 1));
+		const float pn = (float)(int32_t)(RG(r, -r) - RG(r, -1) - RG(1, -r) + RG(1, -1));
+		const float np = (float)(int32_t)(RG(-r, r) - RG(-r, 1) - RG(-1, r) + RG(-1, 1));
+		const float nn = (float)(int32_t)(RG(-r, -r) - RG(-r, -1) - RG(-1, -r) + RG(-1, -1));
+#undef RG
+		const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
+		bc[e] = (b < a ? b : a) / div;
+	}
+	__syncthreads();
+	for(int e = tid; e < FT_W * FT_H; e += 256) {
+		const int ty = e / FT_W, tx = e - ty * FT_W;
+		const int x = x0 + tx, y = y0 + ty;
+		if(x >= w || y >= h) continue;
+		const float* p = bc + (ty + 1) * BW + tx + 1;
+		const float v = p[0];
+		if(bc_out) bc_out[z * n + (size_t)y * w + x] = v;
+		if(v < thr) continue;
+		if(p[-1] > v || p[1] > v || p[-BW] > v || p[BW] > v) {
+			atomicAdd(&counter[3 * z + 2], 1);
+			continue;
+		}
+		const int slot = atomicAdd(&cand_count[z], 1);
+		cand[z * n + slot] = (uint32_t)(y * w + x);
+	}
+}
+
+// blobcenter != nullptr: list from a materialised blobCenter image (vp_bloblist).  Otherwise fused from the SAT
+// (vp_blobcenter_list): blobCenter lives in LDS only, `bc_out` (optional) receives the debug view.
+static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
+		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, const ListScratch& ws) {
 	hipStream_t s = ctx->streams[stream];
 	VP_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t) * 3 * batch, s)); // main.cpp:283-288
 	VP_CHECK_HIP(hipMemsetAsync(ws.cand_count, 0, sizeof(int32_t) * batch, s));
-	k_detect<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, s>>>(blobcenter, ws.cand, ws.cand_count, counter, w, h, thr);
-	VP_TRY(vp_launch_ok("blobList detect"));
 	uint32_t* idx_work = (order == VP_ORDER_RASTER || !idx) ? ws.idx : idx;
-	k_emit<<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
-			w, h, min_score, radius, max_matches);
+	if(blobcenter) {
+		k_detect<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, s>>>(blobcenter, ws.cand, ws.cand_count, counter, w, h, thr);
+		VP_TRY(vp_launch_ok("blobList detect"));
+		k_emit<false><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
+				w, h, min_score, radius, max_matches, 0);
+	} else {
+		const int halo = circle_radius + 1;
+		const size_t lds = sizeof(uint32_t) * (size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + sizeof(float) * (FT_W + 2) * (FT_H + 2);
+		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
+		if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		k_circle_detect<<<dim3(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch), 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr);
+		VP_TRY(vp_launch_ok("circle+detect"));
+		k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
+				w, h, min_score, radius, max_matches, circle_radius);
+	}
 	VP_TRY(vp_launch_ok("blobList emit"));
 	if(order == VP_ORDER_RASTER) {
 		const dim3 grid(vp_div_up(max_matches, 256), batch);
@@ -257,7 +336,7 @@ extern "C" int vp_bloblist(VpContext* ctx, int stream, const uint8_t* flat, cons
 	ListScratch ws;
 	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, false, &ws));
 	VpStageTimer t(ctx, stream, "blobList");
-	return list_from_blobcenter(ctx, stream, flat, blobcenter, w, h, batch, circ_threshold, min_score, radius, max_matches, order, matches, idx, counter, ws);
+	return list_from_blobcenter(ctx, stream, flat, blobcenter, nullptr, 0, nullptr, w, h, batch, circ_threshold, min_score, radius, max_matches, order, matches, idx, counter, ws);
 }
 
 extern "C" int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* flat, const int32_t* sat, int w, int h, int batch,
@@ -268,11 +347,9 @@ extern "C" int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* fla
 	VP_REQUIRE(circle_radius >= 0, "vp_blobcenter_list: bad circle radius");
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	ListScratch ws;
-	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, blobcenter_out == nullptr, &ws));
+	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, false, &ws));
 	VpStageTimer t(ctx, stream, "satBlobCenter+blobList");
-	float* bc = blobcenter_out ? blobcenter_out : ws.blobcenter;
-	VP_TRY(launch_circle(ctx, stream, sat, w, h, circle_radius, batch, bc));
-	return list_from_blobcenter(ctx, stream, flat, bc, w, h, batch, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter, ws);
+	return list_from_blobcenter(ctx, stream, flat, nullptr, sat, circle_radius, blobcenter_out, w, h, batch, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter, ws);
 }
 
 // ---------------------------------------------------------------- validation kernels -------------------------------
