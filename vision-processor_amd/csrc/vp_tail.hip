@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void k_copy_back(const uint8_t* __restrict__ r
 // Out-of-image ring positions take the value of the clamped position, exactly what the clamped reads of the reference return.
 constexpr int FT_W = 64, FT_H = 32;
 
+// NE: region elements per thread held in registers so that ALL global loads are in flight before the first LDS store
+// (a plain load->store loop with run-time bounds is not unrolled and pays one memory round trip per iteration); NE = 0
+// selects that plain loop for very large radii.
+template<int NE>
 __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
 		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r, float thr) {
 	extern __shared__ __attribute__((aligned(16))) char smem_tail[];
@@ -246,9 +250,28 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	const int32_t* sat = sat_all + z * n;
 	const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
 	const int tid = threadIdx.x;
-	for(int ry = tid >> 6; ry < RH; ry += 4) {
-		const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
-		for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - halo + rx, 0, w - 1)];
+	if(NE > 0) {
+		uint32_t v[NE > 0 ? NE : 1];
+		const int total = RW * RH, dq = 256 / RW, dr = 256 - dq * RW;
+		int ry = tid / RW, rx = tid - ry * RW;
+#pragma unroll
+		for(int k = 0; k < NE; k++) {
+			v[k] = (k * 256 + tid < total) ? (uint32_t)sat[(size_t)vp_clampi(y0 - halo + ry, 0, h - 1) * w + vp_clampi(x0 - halo + rx, 0, w - 1)] : 0u;
+			ry += dq;
+			rx += dr;
+			if(rx >= RW) {
+				rx -= RW;
+				ry++;
+			}
+		}
+#pragma unroll
+		for(int k = 0; k < NE; k++)
+			if(k * 256 + tid < total) region[k * 256 + tid] = v[k];
+	} else {
+		for(int ry = tid >> 6; ry < RH; ry += 4) {
+			const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
+			for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - halo + rx, 0, w - 1)];
+		}
 	}
 	__syncthreads();
 	const float div = (float)(r * r);
@@ -302,8 +325,18 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 		const int halo = circle_radius + 1;
 		const size_t lds = sizeof(uint32_t) * (size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + sizeof(float) * (FT_W + 2) * (FT_H + 2);
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
-		if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		k_circle_detect<<<dim3(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch), 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr);
+		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + 255) / 256;
+		const dim3 grid(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch);
+#define VP_CD(N) \
+		do { \
+			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+			k_circle_detect<N><<<grid, 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
+		} while(0)
+		if(per_thread <= 14) VP_CD(14);
+		else if(per_thread <= 20) VP_CD(20);
+		else if(per_thread <= 32) VP_CD(32);
+		else VP_CD(0);
+#undef VP_CD
 		VP_TRY(vp_launch_ok("circle+detect"));
 		k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
 				w, h, min_score, radius, max_matches, circle_radius);
