@@ -13,6 +13,7 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -Wall -pthread
 HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
 HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) include/vp_hip.h
 HOST_SRCS := $(PKG)/host/synth.cpp $(PKG)/host/geometry.cpp
+FACADE_SRCS := $(PKG)/host/frame_loop.cpp $(PKG)/host/Resources.cpp $(PKG)/host/opencl.cpp
 
 .PHONY: all hip host oracle facade clean
 all: hip host oracle facade
@@ -30,8 +31,8 @@ facade: $(PKG)/host/vp_frame_loop
 else
 facade:
 endif
-$(PKG)/host/vp_frame_loop: $(PKG)/host/frame_loop.cpp $(wildcard $(PKG)/host/*.h) $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
-	g++ $(CXXFLAGS) -o $@ $(PKG)/host/frame_loop.cpp -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..'
+$(PKG)/host/vp_frame_loop: $(FACADE_SRCS) $(wildcard $(PKG)/host/*.h) $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
+	g++ $(CXXFLAGS) -o $@ $(FACADE_SRCS) -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -s -C oracle oracle ref

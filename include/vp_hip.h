@@ -109,6 +109,12 @@ int vp_memset_device(VpContext* ctx, int stream, void* dst_d, int value, size_t 
  * raw: batch x (Bayer: 2qh x 2qw bytes | BGR: qh x qw x 3 bytes).  planes: batch x 4 x qh x qw (plane 3 untouched for BGR). */
 int vp_raw2quad(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int batch, uint8_t* planes);
 
+/* The same two stages for four separately allocated plane images, as Resources::raw2quad hands them out
+ * (four OpenCL::acquire calls, Resources.cpp:139-140); one frame per call.  plane3 may be NULL for BGR. */
+int vp_raw2quad4(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, uint8_t* plane0, uint8_t* plane1, uint8_t* plane2, uint8_t* plane3);
+int vp_resample4(VpContext* ctx, int stream, const uint8_t* plane0, const uint8_t* plane1, const uint8_t* plane2, const uint8_t* plane3, int layout, int qw, int qh,
+		const VpCameraModel* model, float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, uint8_t* flat);
+
 /* resampling + field2image (resampling.cl:29-100; Resources.cpp:159).  planes as written by vp_raw2quad.
  * flat: batch x fh x fw RGBA8 (delta-RGB, alpha 255). */
 int vp_resample(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, const VpCameraModel* model,

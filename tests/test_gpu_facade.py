@@ -1,0 +1,74 @@
+"""The C++ host facade (vision-processor_amd/host: opencl.h / Resources / frame loop mirroring main.cpp:251-317) run as its own
+process on the GPU, its blob lists checked against the CPU oracle frame by frame."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+BIN = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_frame_loop")
+
+
+def run_loop(cfg, frames, seed, mode, tmp_path):
+    dump = str(tmp_path / f"{cfg.name}_{mode}.bin")
+    args = [BIN, str(cfg.layout), str(cfg.qw), str(cfg.qh), str(cfg.cam_height), str(cfg.visible_len), str(cfg.distortion), str(cfg.field_len), str(cfg.field_wid),
+            str(frames), str(0x5EED0000 + seed), str(cfg.n_robots), str(cfg.n_balls), mode]
+    if mode == "direct":
+        args += [repr(cfg.field_scale), repr(cfg.off_x), repr(cfg.off_y), str(cfg.fw), str(cfg.fh)]
+    args.append(dump)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    recs = []
+    with open(dump, "rb") as f:
+        while True:
+            hdr = f.read(32)
+            if len(hdr) < 32:
+                break
+            frame_id, n, c0, c1, c2, fw, fh, _ = struct.unpack("8i", hdr)
+            fs, ox, oy, _ = struct.unpack("4f", f.read(16))
+            m = np.frombuffer(f.read(22 * n), O.MATCH_DTYPE)
+            pos = np.frombuffer(f.read(8 * n), np.float32).reshape(n, 2)
+            recs.append(dict(frame=frame_id, counter=np.array([c0, c1, c2], np.int32), fw=fw, fh=fh, fs=fs, ox=ox, oy=oy, matches=m, pos=pos))
+    return recs, out.stdout
+
+
+def check_against_oracle(port, cfg, recs, seed):
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    for k, r in enumerate(recs):
+        fs = np.float32(r["fs"])
+        o = int(np.ceil(np.float32(25.0) / fs)) // 3
+        rad = int(np.ceil(np.float32(20.0) / fs))
+        R = int(np.floor(np.float32(20.0) / fs))
+        raw = cfg.synth(seed + k)
+        m, idx, cnt = port.frame(raw, cfg.layout, cfg.qw, cfg.qh, model, 180.0, float(fs), r["ox"], r["oy"], 1, r["fw"], r["fh"], o, rad, R, 15.0, 0.0, 2000)
+        assert np.array_equal(cnt, r["counter"]), (k, cnt, r["counter"])
+        assert m.tobytes() == r["matches"].tobytes(), f"frame {k}: blob records differ from the oracle"
+        want = np.stack([m["x"] * fs + np.float32(r["ox"]), m["y"] * fs + np.float32(r["oy"])], 1).astype(np.float32)  # Perspective.cpp:127-129
+        assert np.array_equal(want, r["pos"], equal_nan=True)
+        assert len(m) > 3
+
+
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.CFG1], ids=lambda c: c.name)
+def test_frame_loop_direct_scalars(port, cfg, tmp_path):
+    recs, stdout = run_loop(cfg, 3, 50, "direct", tmp_path)
+    assert len(recs) == 3 and "ms" in stdout  # printRuntimes output
+    check_against_oracle(port, cfg, recs, 50)
+
+
+def test_frame_loop_geometry_check(port, tmp_path):
+    """Kernel scalars produced by the Eigen-free Perspective::geometryCheck; the oracle is fed the same scalars."""
+    cfg = cfgs.T_MID
+    recs, _ = run_loop(cfg, 2, 60, "calib", tmp_path)
+    assert len(recs) == 2
+    r = recs[0]
+    # 3000 mm of the plane over 320 quad pixels, distortion shrinks the footprint a little: ~9-10 mm per quad pixel
+    assert 8.0 < r["fs"] < 11.0 and r["fw"] % 2 == 0 and r["fh"] % 2 == 0
+    check_against_oracle(port, cfg, recs, 60)

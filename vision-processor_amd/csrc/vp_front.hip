@@ -10,7 +10,12 @@
 
 // ---------------------------------------------------------------- raw2quad ----------------------------------------
 // Bayer, vector path: one thread de-interleaves four 2x2 cells = 8 B of each of two sensor rows into 4 B per plane.
-__global__ __launch_bounds__(256) void k_raw2quad_bayer4(const uint8_t* __restrict__ raw, uint8_t* __restrict__ planes, int qw, int qh) {
+struct Planes4 {
+	uint8_t* p[4];
+	size_t bstride; // bytes between consecutive frames of one plane
+};
+
+__global__ __launch_bounds__(256) void k_raw2quad_bayer4(const uint8_t* __restrict__ raw, const Planes4 pl, int qw, int qh) {
 	const int x4 = blockIdx.x * 64 + threadIdx.x;
 	const int y = blockIdx.y * 4 + threadIdx.y;
 	if(x4 * 4 >= qw || y >= qh) return;
@@ -22,52 +27,67 @@ __global__ __launch_bounds__(256) void k_raw2quad_bayer4(const uint8_t* __restri
 	// v_perm_b32: selector bytes 0-3 pick from the 2nd operand, 4-7 from the 1st
 	const uint32_t p0 = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u), p1 = __builtin_amdgcn_perm(a.y, a.x, 0x07050301u);
 	const uint32_t p2 = __builtin_amdgcn_perm(b.y, b.x, 0x06040200u), p3 = __builtin_amdgcn_perm(b.y, b.x, 0x07050301u);
-	uint8_t* out = planes + (size_t)blockIdx.z * 4 * q + (size_t)y * qw + 4 * (size_t)x4;
-	*reinterpret_cast<uint32_t*>(out) = p0;
-	*reinterpret_cast<uint32_t*>(out + q) = p1;
-	*reinterpret_cast<uint32_t*>(out + 2 * q) = p2;
-	*reinterpret_cast<uint32_t*>(out + 3 * q) = p3;
+	const size_t o = (size_t)blockIdx.z * pl.bstride + (size_t)y * qw + 4 * (size_t)x4;
+	*reinterpret_cast<uint32_t*>(pl.p[0] + o) = p0;
+	*reinterpret_cast<uint32_t*>(pl.p[1] + o) = p1;
+	*reinterpret_cast<uint32_t*>(pl.p[2] + o) = p2;
+	*reinterpret_cast<uint32_t*>(pl.p[3] + o) = p3;
 }
 
 // any width / BGR: one thread per cell
 template<bool BGR>
-__global__ __launch_bounds__(256) void k_raw2quad_scalar(const uint8_t* __restrict__ raw, uint8_t* __restrict__ planes, int qw, int qh) {
+__global__ __launch_bounds__(256) void k_raw2quad_scalar(const uint8_t* __restrict__ raw, const Planes4 pl, int qw, int qh) {
 	const int x = blockIdx.x * 64 + threadIdx.x;
 	const int y = blockIdx.y * 4 + threadIdx.y;
 	if(x >= qw || y >= qh) return;
 	const size_t q = (size_t)qw * qh;
-	uint8_t* out = planes + (size_t)blockIdx.z * 4 * q + (size_t)y * qw + x;
+	const size_t o = (size_t)blockIdx.z * pl.bstride + (size_t)y * qw + x;
 	if(BGR) {
 		const uint8_t* p = raw + (size_t)blockIdx.z * 3 * q + 3 * ((size_t)y * qw + x);
-		out[0] = p[0];
-		out[q] = p[1];
-		out[2 * q] = p[2];
+		pl.p[0][o] = p[0];
+		pl.p[1][o] = p[1];
+		pl.p[2][o] = p[2];
 	} else {
 		const size_t row = 2 * (size_t)qw;
 		const uint8_t* p = raw + (size_t)blockIdx.z * 4 * q + (size_t)(2 * y) * row + 2 * (size_t)x;
-		out[0] = p[0];
-		out[q] = p[1];
-		out[2 * q] = p[row];
-		out[3 * q] = p[row + 1];
+		pl.p[0][o] = p[0];
+		pl.p[1][o] = p[1];
+		pl.p[2][o] = p[row];
+		pl.p[3][o] = p[row + 1];
 	}
+}
+
+static int raw2quad_launch(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int batch, const Planes4& pl) {
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "raw2quad");
+	hipStream_t s = ctx->streams[stream];
+	const dim3 block(64, 4);
+	bool al = (reinterpret_cast<uintptr_t>(raw) & 7) == 0 && (pl.bstride & 3) == 0;
+	for(int c = 0; c < 4; c++) al = al && (reinterpret_cast<uintptr_t>(pl.p[c]) & 3) == 0;
+	if(layout == VP_LAYOUT_BGR) {
+		k_raw2quad_scalar<true><<<dim3(vp_div_up(qw, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, pl, qw, qh);
+	} else if(qw % 4 == 0 && al) {
+		k_raw2quad_bayer4<<<dim3(vp_div_up(qw / 4, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, pl, qw, qh);
+	} else {
+		k_raw2quad_scalar<false><<<dim3(vp_div_up(qw, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, pl, qw, qh);
+	}
+	return vp_launch_ok("raw2quad");
 }
 
 extern "C" int vp_raw2quad(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int batch, uint8_t* planes) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(raw && planes && qw > 0 && qh > 0 && batch > 0 && layout >= 0 && layout <= 2, "vp_raw2quad: bad arguments");
 	VP_REQUIRE(batch <= 65535, "vp_raw2quad: batch %d > 65535", batch);
-	VP_CHECK_HIP(hipSetDevice(ctx->device));
-	VpStageTimer t(ctx, stream, "raw2quad");
-	hipStream_t s = ctx->streams[stream];
-	const dim3 block(64, 4);
-	if(layout == VP_LAYOUT_BGR) {
-		k_raw2quad_scalar<true><<<dim3(vp_div_up(qw, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, planes, qw, qh);
-	} else if(qw % 4 == 0 && (reinterpret_cast<uintptr_t>(raw) & 7) == 0 && (reinterpret_cast<uintptr_t>(planes) & 3) == 0) {
-		k_raw2quad_bayer4<<<dim3(vp_div_up(qw / 4, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, planes, qw, qh);
-	} else {
-		k_raw2quad_scalar<false><<<dim3(vp_div_up(qw, 64), vp_div_up(qh, 4), batch), block, 0, s>>>(raw, planes, qw, qh);
-	}
-	return vp_launch_ok("raw2quad");
+	const size_t q = (size_t)qw * qh;
+	const Planes4 pl = {{planes, planes + q, planes + 2 * q, planes + 3 * q}, 4 * q};
+	return raw2quad_launch(ctx, stream, raw, layout, qw, qh, batch, pl);
+}
+
+extern "C" int vp_raw2quad4(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, uint8_t* plane0, uint8_t* plane1, uint8_t* plane2, uint8_t* plane3) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(raw && plane0 && plane1 && plane2 && (plane3 || layout == VP_LAYOUT_BGR) && qw > 0 && qh > 0 && layout >= 0 && layout <= 2, "vp_raw2quad4: bad arguments");
+	const Planes4 pl = {{plane0, plane1, plane2, plane3 ? plane3 : plane2}, 0};
+	return raw2quad_launch(ctx, stream, raw, layout, qw, qh, 1, pl);
 }
 
 // ---------------------------------------------------------------- resampling --------------------------------------
@@ -75,6 +95,8 @@ struct ResampleArgs {
 	VpCameraModel m;
 	float height, fs, ox, oy;
 	int qw, qh, fw, fh;
+	const uint8_t* pl[4]; // plane sources (unused when sampling the raw buffer)
+	size_t pl_bstride;
 };
 
 // resampling.cl:29-47
@@ -98,16 +120,22 @@ __device__ __forceinline__ void field2image(const VpCameraModel& m, float fx, fl
 	oy = m.f * uy + m.p[1];
 }
 
+// one frame's source: the raw sensor buffer, or the four materialised quad planes
+struct Src {
+	const uint8_t* raw;
+	const uint8_t* p[4];
+};
+
 // texel (i, j) of quad plane `ch`, either from materialised planes or straight from the raw sensor buffer
 template<int LAYOUT, bool FROM_RAW>
-__device__ __forceinline__ uint32_t texel(const uint8_t* __restrict__ src, int ch, int i, int j, int qw, int qh) {
-	if(!FROM_RAW) return src[(size_t)ch * qw * qh + (size_t)j * qw + i];
-	if(LAYOUT == VP_LAYOUT_BGR) return src[3 * ((size_t)j * qw + i) + ch];
-	return src[(size_t)(2 * j + (ch >> 1)) * (2 * (size_t)qw) + 2 * (size_t)i + (ch & 1)]; // raw2quad.cl:31-37
+__device__ __forceinline__ uint32_t texel(const Src& src, int ch, int i, int j, int qw, int qh) {
+	if(!FROM_RAW) return src.p[ch][(size_t)j * qw + i];
+	if(LAYOUT == VP_LAYOUT_BGR) return src.raw[3 * ((size_t)j * qw + i) + ch];
+	return src.raw[(size_t)(2 * j + (ch >> 1)) * (2 * (size_t)qw) + 2 * (size_t)i + (ch & 1)]; // raw2quad.cl:31-37
 }
 
 template<int LAYOUT, int MODE, bool FROM_RAW>
-__device__ __forceinline__ uint32_t sample(const uint8_t* __restrict__ src, int ch, float u, float v, int qw, int qh) {
+__device__ __forceinline__ uint32_t sample(const Src& src, int ch, float u, float v, int qw, int qh) {
 	if(MODE == VP_SAMPLER_NEAREST) {
 		const int x = vp_clampi((int)floorf(u), 0, qw - 1), y = vp_clampi((int)floorf(v), 0, qh - 1);
 		return texel<LAYOUT, FROM_RAW>(src, ch, x, y, qw, qh);
@@ -181,7 +209,10 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 	const int gx = blockIdx.x * 64 + threadIdx.x;
 	const int gy = blockIdx.y * 4 + threadIdx.y;
 	if(gx >= a.fw || gy >= a.fh) return;
-	const uint8_t* s = src + (size_t)blockIdx.z * src_frame_bytes;
+	Src s;
+	s.raw = src + (size_t)blockIdx.z * src_frame_bytes;
+#pragma unroll
+	for(int c = 0; c < 4; c++) s.p[c] = a.pl[c] + (size_t)blockIdx.z * a.pl_bstride;
 	float px, py;
 	field2image(a.m, (float)gx * a.fs + a.ox, (float)gy * a.fs + a.oy, a.height, px, py); // resampling.cl:53
 	uint32_t r, g, b;
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 		b = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px, py, a.qw, a.qh);
 	} else if(FROM_RAW && MODE == VP_SAMPLER_BILINEAR_RTZ && a.qw >= 4) {
 		uint32_t p[4];
-		sample_bayer4(s, px, py, a.qw, a.qh, p);
+		sample_bayer4(s.raw, px, py, a.qw, a.qh, p);
 		if(LAYOUT == VP_LAYOUT_RGGB) { r = p[0]; g = p[1] / 2 + p[2] / 2; b = p[3]; }
 		else { r = p[1]; g = p[0] / 2 + p[3] / 2; b = p[2]; }
 	} else if(LAYOUT == VP_LAYOUT_RGGB) { // :64-71
@@ -227,7 +258,9 @@ __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restri
 	if(gx >= fw || gy >= fh) return;
 	const float2 pos = map[(size_t)gy * fw + gx];
 	const float px = pos.x, py = pos.y;
-	const uint8_t* s = raw + (size_t)blockIdx.z * src_frame_bytes;
+	Src s;
+	s.raw = raw + (size_t)blockIdx.z * src_frame_bytes;
+	s.p[0] = s.p[1] = s.p[2] = s.p[3] = nullptr;
 	uint32_t r, g, b;
 	if(LAYOUT == VP_LAYOUT_BGR) {
 		r = sample<LAYOUT, MODE, true>(s, 2, px, py, qw, qh);
@@ -235,7 +268,7 @@ __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restri
 		b = sample<LAYOUT, MODE, true>(s, 0, px, py, qw, qh);
 	} else if(MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
 		uint32_t p[4];
-		sample_bayer4(s, px, py, qw, qh, p);
+		sample_bayer4(s.raw, px, py, qw, qh, p);
 		if(LAYOUT == VP_LAYOUT_RGGB) { r = p[0]; g = p[1] / 2 + p[2] / 2; b = p[3]; }
 		else { r = p[1]; g = p[0] / 2 + p[3] / 2; b = p[2]; }
 	} else if(LAYOUT == VP_LAYOUT_RGGB) {
@@ -298,10 +331,10 @@ extern "C" int vp_resample_raw_mapped(VpContext* ctx, int stream, const uint8_t*
 }
 
 template<bool FROM_RAW>
-static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, int layout, int qw, int qh, const VpCameraModel* model,
+static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, const uint8_t* const* planes4, int layout, int qw, int qh, const VpCameraModel* model,
 		float height, float fs, float ox, float oy, int mode, int fw, int fh, int batch, uint8_t* flat, const char* name) {
 	VP_TRY(vp_check_ctx(ctx, stream));
-	VP_REQUIRE(src && flat && model, "%s: null pointer", name);
+	VP_REQUIRE((src || planes4) && flat && model, "%s: null pointer", name);
 	VP_REQUIRE(qw > 0 && qh > 0 && fw > 0 && fh > 0 && batch > 0 && batch <= 65535, "%s: bad shape", name);
 	VP_REQUIRE(layout >= 0 && layout <= 2 && (mode == VP_SAMPLER_NEAREST || mode == VP_SAMPLER_BILINEAR_RTZ), "%s: bad layout/sampler mode", name);
 	VP_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 3) == 0, "%s: flat must be 4-byte aligned", name);
@@ -319,6 +352,8 @@ static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, int
 	a.fh = fh;
 	const size_t q = (size_t)qw * qh;
 	const size_t frame_bytes = FROM_RAW ? (layout == VP_LAYOUT_BGR ? 3 * q : 4 * q) : 4 * q;
+	for(int c = 0; c < 4; c++) a.pl[c] = FROM_RAW ? nullptr : (planes4 ? planes4[c] : src + c * q);
+	a.pl_bstride = planes4 ? 0 : 4 * q;
 	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), batch), block(64, 4);
 	hipStream_t s = ctx->streams[stream];
 #define VP_RS(L, M) k_resample<L, M, FROM_RAW><<<grid, block, 0, s>>>(src, flat, a, frame_bytes)
@@ -337,10 +372,17 @@ static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, int
 
 extern "C" int vp_resample(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, const VpCameraModel* model,
 		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat) {
-	return resample_dispatch<false>(ctx, stream, planes, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "resampling");
+	return resample_dispatch<false>(ctx, stream, planes, nullptr, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "resampling");
+}
+
+extern "C" int vp_resample4(VpContext* ctx, int stream, const uint8_t* plane0, const uint8_t* plane1, const uint8_t* plane2, const uint8_t* plane3, int layout, int qw, int qh,
+		const VpCameraModel* model, float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, uint8_t* flat) {
+	VP_REQUIRE(plane0 && plane1 && plane2 && (plane3 || layout == VP_LAYOUT_BGR), "vp_resample4: null plane");
+	const uint8_t* pl[4] = {plane0, plane1, plane2, plane3 ? plane3 : plane2};
+	return resample_dispatch<false>(ctx, stream, nullptr, pl, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, 1, flat, "resampling");
 }
 
 extern "C" int vp_resample_raw(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const VpCameraModel* model,
 		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat) {
-	return resample_dispatch<true>(ctx, stream, raw, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "raw2quad+resampling");
+	return resample_dispatch<true>(ctx, stream, raw, nullptr, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "raw2quad+resampling");
 }

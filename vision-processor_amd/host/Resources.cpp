@@ -1,0 +1,50 @@
+#include "Resources.h"
+
+#include <vector>
+
+std::shared_ptr<RawImage> SyntheticCamera::readImage() {
+	if(frame >= frames) return nullptr;
+	const bool bgr = fmt->layout == VP_LAYOUT_BGR;
+	std::vector<unsigned char> raw((size_t)qw * qh * fmt->pixelSize());
+	if(vp_synth_frame(&model, fmt->layout, qw, qh, planeHeight, fieldLen, fieldWid, seed + (uint32_t)frame, robots, balls, noise, raw.data()) != VP_OK) FATAL("synthetic frame generation failed");
+	(void)bgr;
+	frame++;
+	return std::make_shared<RawImage>(fmt, qw, qh, getTime(), raw.data());
+}
+
+Resources::Resources(std::unique_ptr<SyntheticCamera> cam, int camId, float geometryTolerance): camera(std::move(cam)), camId(camId) {
+	openCl = std::make_shared<OpenCL>();
+	perspective = std::make_shared<vp::Perspective>(camId, geometryTolerance);
+	const char* layout = camera->format().kernelOptions; // Resources.cpp:121-126: the format-dependent kernels get -DRGGB/-DGRBG/-DBGR
+	raw2quadKernel = openCl->compile(kernel_raw2quad_cl, layout);
+	resampling = openCl->compile(kernel_resampling_cl, layout);
+	gradientDot = openCl->compile(kernel_gradientDot_cl);
+	satHorizontal = openCl->compile(kernel_satHorizontal_cl);
+	satVertical = openCl->compile(kernel_satVertical_cl);
+	satBlobCenter = openCl->compile(kernel_satBlobCenter_cl);
+}
+
+void Resources::raw2quad(const RawImage& img, std::shared_ptr<CLImage>* channels) {
+	for(int c = 0; c < 4; c++) channels[c] = openCl->acquire(&PixelFormat::U8, img.width, img.height, img.name);
+	openCl->await(raw2quadKernel, cl::EnqueueArgs(cl::NDRange(img.width, img.height)), img.buffer, channels[0]->image, channels[1]->image, channels[2]->image, channels[3]->image);
+}
+
+void Resources::rgba2blobCenter(const std::shared_ptr<CLImage>* channels, std::shared_ptr<CLImage>& flat, std::shared_ptr<CLImage>& gradDot, std::shared_ptr<CLImage>& blobCenter) {
+	const vp::Perspective& p = *perspective;
+	const int fw = p.reprojectedFieldSize.x, fh = p.reprojectedFieldSize.y;
+	const std::string& name = channels[0]->name;
+	const cl::NDRange field(fw, fh);
+	flat = openCl->acquire(&PixelFormat::RGBA8, fw, fh, name);
+	gradDot = openCl->acquire(&PixelFormat::F32, fw, fh, name);
+	// the reference's two SAT images: same (format, size) pool traffic, contents unused here (the table is int32 and private)
+	std::shared_ptr<CLImage> gradDotHor = openCl->acquire(&PixelFormat::F32, fw, fh, name);
+	std::shared_ptr<CLImage> gradDotSat = openCl->acquire(&PixelFormat::F32, fw, fh, name);
+	blobCenter = openCl->acquire(&PixelFormat::F32, fw, fh, name);
+
+	cl::Event e1 = openCl->run(resampling, cl::EnqueueArgs(field), channels[0]->image, channels[1]->image, channels[2]->image, channels[3]->image, flat->image, p.getCLCameraModel(),
+			(float)maxBotHeight, p.fieldScale, p.visibleFieldExtent[0], p.visibleFieldExtent[2]);
+	cl::Event e2 = openCl->run(gradientDot, cl::EnqueueArgs(e1, field), flat->image, gradDot->image, p.gradOffset());
+	cl::Event e3 = openCl->run(satHorizontal, cl::EnqueueArgs(e2, cl::NDRange(fh)), gradDot->image, gradDotHor->image);
+	cl::Event e4 = openCl->run(satVertical, cl::EnqueueArgs(e3, cl::NDRange(fw)), gradDotHor->image, gradDotSat->image);
+	openCl->await(satBlobCenter, cl::EnqueueArgs(e4, field), gradDotSat->image, blobCenter->image, p.circleRadius());
+}

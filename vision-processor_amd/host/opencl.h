@@ -1,0 +1,255 @@
+// HIP-backed host facade with the call surface of the reference's src/opencl.h (classes OpenCL, CLArray, CLMap, RawImage,
+// CLImage, CLImageMap, PixelFormat) so that the per-frame loop of src/main.cpp:262-317 and src/Resources.cpp:138-164 can be
+// written against it unchanged.  Nothing here compiles or ships OpenCL: a `cl::Kernel` is a tag naming one entry point of
+// the C ABI (include/vp_hip.h), `OpenCL::run` forwards the argument pack to it, images and buffers are plain HIP memory.
+//
+// Differences a maintainer will notice (all deliberate):
+//   * CLImageMap has no `cv::Mat cv` member (OpenCV is not a dependency of the hot path); rowPitch == width.
+//   * map()/unmap() are a device<->pinned-host copy on the context stream (the reference's blocking clEnqueueMapBuffer).
+//   * the intermediate SAT is an int32 table owned by Resources::rgba2blobCenter, never exposed (the reference keeps its
+//     two F32 SAT images private to that function as well, Resources.cpp:155-156).
+// Errors follow the reference: any failure is FATAL = message on stderr + exit(1) (src/log.h:21).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vp_hip.h"
+
+#define LOG(msg) do { std::cout << "[LOG] " << msg << std::endl; } while(0)
+#define WARN(msg) do { std::cerr << "[WARN] " << __FILE__ << ":" << __LINE__ << " " << msg << std::endl; } while(0)
+#define FATAL(msg) do { std::cerr << "[FATAL] " << __FILE__ << ":" << __LINE__ << " " << msg << std::endl; exit(1); } while(0)
+#define VP_OR_FATAL(expr) do { if((expr) != VP_OK) FATAL(#expr << ": " << vp_last_error()); } while(0)
+
+typedef VpCameraModel CLCameraModel; // Perspective.h:22-29
+
+// ---- the sliver of the cl:: namespace the call sites use ------------------------------------------------------------------
+namespace cl {
+enum class KernelId { none, raw2quad, resampling, gradientDot, satHorizontal, satVertical, satBlobCenter, blobList, blobScore, blobCenter };
+struct Kernel {
+	KernelId id = KernelId::none;
+	int layout = VP_LAYOUT_RGGB; // from the -DRGGB / -DGRBG / -DBGR compile option (opencl.cpp:29-31)
+};
+struct NDRange {
+	size_t d[2] = {1, 1};
+	NDRange() = default;
+	explicit NDRange(size_t x) { d[0] = x; }
+	NDRange(size_t x, size_t y) { d[0] = x; d[1] = y; }
+};
+struct Event {
+	VpContext* ctx = nullptr;
+	int stream = 0;
+};
+struct EnqueueArgs {
+	NDRange global;
+	explicit EnqueueArgs(NDRange g): global(g) {}
+	EnqueueArgs(const Event&, NDRange g): global(g) {} // one in-order stream: the explicit event chain is redundant (opencl.cpp:48)
+};
+struct Buffer { void* dptr = nullptr; };
+struct Image2D { void* dptr = nullptr; int width = 0, height = 0; };
+} // namespace cl
+
+class PixelFormat { // opencl.h:30-56
+public:
+	static const PixelFormat RGBA8, U8, F32, NV12, RGGB8, GRBG8, BGR8;
+	int pixelSize() const { return stride * rowStride; }
+	const int stride;
+	const int rowStride;
+	const bool color;
+	const int layout; // VpLayout for raw formats, -1 otherwise
+	const char* kernelOptions;
+private:
+	PixelFormat(int stride, int rowStride, bool color, int layout, const char* options): stride(stride), rowStride(rowStride), color(color), layout(layout), kernelOptions(options) {}
+};
+
+class CLImage;
+class RawImage;
+
+class OpenCL { // opencl.h:70-112
+public:
+	OpenCL();
+	~OpenCL();
+
+	cl::Kernel compile(const char* code, const std::string& options = "");
+
+	template<typename... Ts>
+	cl::Event run(cl::Kernel kernel, const cl::EnqueueArgs& args, Ts... ts) {
+		std::vector<Arg> packed;
+		(packed.push_back(Arg(ts)), ...);
+		dispatch(kernel, args, packed);
+		return cl::Event{ctx, 0};
+	}
+	template<typename... Ts>
+	void await(cl::Kernel kernel, const cl::EnqueueArgs& args, Ts... ts) { wait(run(kernel, args, std::forward<Ts>(ts)...)); }
+
+	static void wait(const cl::Event& event);
+	void printRuntimes();
+	void clearEvents();
+
+	std::shared_ptr<CLImage> acquire(const PixelFormat* format, int width, int height, const std::string& name);
+	std::shared_ptr<RawImage> acquireNV12(int width, int height);
+
+	// extensions the hot path uses
+	void setSamplerMode(int mode) { samplerMode = mode; }
+	void setSatVariant(int v) { satVariant = v; }
+	void setListOrder(int o) { listOrder = o; }
+	static VpContext* context() { return ctx; }
+
+private:
+	struct Arg {
+		enum Kind { BUF, IMG, I32, F32, MODEL } kind;
+		void* p = nullptr;
+		int w = 0, h = 0;
+		int i = 0;
+		float f = 0.f;
+		CLCameraModel m{};
+		Arg(const cl::Buffer& b): kind(BUF), p(b.dptr) {}
+		Arg(const cl::Image2D& im): kind(IMG), p(im.dptr), w(im.width), h(im.height) {}
+		Arg(int v): kind(I32), i(v) {}
+		Arg(float v): kind(F32), f(v) {}
+		Arg(const CLCameraModel& v): kind(MODEL), m(v) {}
+	};
+	void dispatch(const cl::Kernel& kernel, const cl::EnqueueArgs& args, const std::vector<Arg>& a);
+
+	static VpContext* ctx;
+	int samplerMode = VP_SAMPLER_BILINEAR_RTZ, satVariant = VP_SAT_TILED, listOrder = VP_ORDER_RASTER;
+	std::map<const PixelFormat*, std::vector<std::shared_ptr<CLImage>>> pool;
+	std::vector<std::shared_ptr<RawImage>> nv12pool;
+	// state handed from one launch to the next inside rgba2blobCenter: the reference's satHorizontal/satVertical pair becomes one
+	// fused launch, so gradientDot only records its arguments and satHorizontal is a no-op (see dispatch())
+	struct { void* flat = nullptr; void* graddot = nullptr; int w = 0, h = 0, offset = 0; } pendingGrad;
+	void* satTable = nullptr;
+	size_t satBytes = 0;
+};
+
+template<typename T>
+class CLMap { // opencl.h:114-152: blocking map in the constructor, blocking unmap in the destructor, move-only
+public:
+	CLMap(void* dptr, void* hptr, int size, bool readBack, bool writeBack): dptr(dptr), map((T*)hptr), size(size), writeBack(writeBack) {
+		if(readBack) VP_OR_FATAL(vp_copy_d2h_sync(OpenCL::context(), 0, hptr, dptr, (size_t)size));
+		else VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
+	}
+	~CLMap() {
+		if(unmoved && writeBack) {
+			VP_OR_FATAL(vp_copy_h2d(OpenCL::context(), 0, dptr, map, (size_t)size));
+			VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
+		}
+	}
+	CLMap(CLMap&& other) noexcept: dptr(other.dptr), map(other.map), size(other.size), writeBack(other.writeBack) { other.unmoved = false; }
+	CLMap(const CLMap&) = delete;
+	CLMap& operator=(const CLMap&) = delete;
+	T*& operator*() { return map; }
+	T* operator->() { return map; }
+	T& operator[](int i) { return map[i]; }
+	const T& operator[](int i) const { return map[i]; }
+
+private:
+	void* dptr;
+	T* map;
+	int size;
+	bool writeBack;
+	bool unmoved = true;
+};
+
+class CLArray { // opencl.h:154-165; opencl.cpp:146-147
+public:
+	explicit CLArray(int size);
+	CLArray(void* data, int size);
+
+	template<typename T> CLMap<T> read() const { return CLMap<T>(buffer.dptr, host.get(), size, true, false); }
+	template<typename T> CLMap<T> write() { return CLMap<T>(buffer.dptr, host.get(), size, false, true); }
+	template<typename T> CLMap<T> readWrite() { return CLMap<T>(buffer.dptr, host.get(), size, true, true); }
+
+	const cl::Buffer buffer;
+	const int size;
+
+private:
+	std::shared_ptr<void> device, host; // released when the last copy of the array goes away
+};
+
+class RawImage: public CLArray { // opencl.h:168-188 -- for Bayer formats width/height count 2x2 cells
+public:
+	RawImage(const PixelFormat* format, int width, int height): CLArray(width * height * format->pixelSize()), format(format), width(width), height(height), name() {}
+	RawImage(const PixelFormat* format, int width, int height, std::string name): CLArray(width * height * format->pixelSize()), format(format), width(width), height(height), name(std::move(name)) {}
+	RawImage(const PixelFormat* format, int width, int height, double timestamp): CLArray(width * height * format->pixelSize()), format(format), width(width), height(height), timestamp(timestamp), name() {}
+	RawImage(const PixelFormat* format, int width, int height, unsigned char* data): CLArray(data, width * height * format->pixelSize()), format(format), width(width), height(height) {}
+	RawImage(const PixelFormat* format, int width, int height, double timestamp, unsigned char* data): CLArray(data, width * height * format->pixelSize()), format(format), width(width), height(height), timestamp(timestamp) {}
+	virtual ~RawImage() = default;
+
+	const PixelFormat* format;
+	const int width;
+	const int height;
+	double timestamp = 0;
+	const std::string name;
+};
+
+template<typename T> class CLImageMap;
+
+class CLImage { // opencl.h:195-212
+public:
+	explicit CLImage(const PixelFormat* format);
+	CLImage(const PixelFormat* format, int width, int height, std::string name);
+
+	template<typename T> CLImageMap<T> read() const { return CLImageMap<T>(*this, true, false); }
+	template<typename T> CLImageMap<T> write() { return CLImageMap<T>(*this, false, true); }
+	template<typename T> CLImageMap<T> readWrite() { return CLImageMap<T>(*this, true, true); }
+
+	cl::Image2D image;
+	const PixelFormat* format;
+	int width;
+	int height;
+	std::string name;
+
+	size_t bytes() const { return (size_t)width * height * format->pixelSize(); }
+	void* hostShadow() const;
+
+private:
+	std::shared_ptr<void> device;
+	mutable std::shared_ptr<void> host; // pinned shadow, allocated on the first map
+};
+
+template<typename T>
+class CLImageMap { // opencl.h:215-262 (without the cv::Mat view)
+public:
+	CLImageMap(const CLImage& image, bool readBack, bool writeBack): dptr(image.image.dptr), bytes(image.bytes()), writeBack(writeBack) {
+		map = (T*)image.hostShadow();
+		bytePitch = (size_t)image.width * image.format->pixelSize();
+		rowPitch = bytePitch / sizeof(T);
+		if(readBack) VP_OR_FATAL(vp_copy_d2h_sync(OpenCL::context(), 0, map, dptr, bytes));
+		else VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
+	}
+	~CLImageMap() {
+		if(unmoved && writeBack) {
+			VP_OR_FATAL(vp_copy_h2d(OpenCL::context(), 0, dptr, map, bytes));
+			VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
+		}
+	}
+	CLImageMap(CLImageMap&& other) noexcept: bytePitch(other.bytePitch), rowPitch(other.rowPitch), dptr(other.dptr), map(other.map), bytes(other.bytes), writeBack(other.writeBack) { other.unmoved = false; }
+	CLImageMap(const CLImageMap&) = delete;
+	CLImageMap& operator=(const CLImageMap&) = delete;
+	T*& operator*() { return map; }
+	T* operator->() { return map; }
+	T& operator[](int i) { return map[i]; }
+	T& operator()(int x, int y) { return map[x + y * rowPitch]; }
+	const T& operator()(int x, int y) const { return map[x + y * rowPitch]; }
+	const T& operator[](int i) const { return map[i]; }
+
+	size_t bytePitch;
+	size_t rowPitch;
+
+private:
+	void* dptr;
+	T* map;
+	size_t bytes;
+	bool writeBack;
+	bool unmoved = true;
+};
