@@ -112,13 +112,13 @@ def main():
                                order=capi.ORDER_RASTER if args.order == "raster" else capi.ORDER_ATOMIC)
 
     # synthetic feeds: distinct seeds per rank and frame, uploaded once (inputs resident in HBM before the timed region)
-    raws = np.stack([cfg.synth(rank * 100000 + i) for i in range(B)])
+    feeds = vp.feeds
+    raws = np.stack([cfg.synth(feeds.feed_seed(rank, i)) for i in range(B)])
     d_raw = torch.from_numpy(raws).cuda()
     flat = torch.empty((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
     sat = torch.empty((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
     # one fixed-size detection record per frame: [counter 3 x i32 | pad 4 | matches mm x 22 | idx mm x u32]
-    rec_bytes = 16 + 22 * mm + 4 * mm
-    rec_bytes += (-rec_bytes) % 16
+    rec_bytes = feeds.record_bytes(mm)
     record = torch.zeros((B, rec_bytes), dtype=torch.uint8, device="cuda")
     # vp_frame wants separate dense arrays; the record tensor is filled by three strided device copies per step
     matches = torch.zeros((B, 22 * mm), dtype=torch.uint8, device="cuda")
@@ -129,10 +129,8 @@ def main():
     def step():
         ctx.frame(params, d_raw, B, flat, sat, matches, counter, idx=idx)
         if world > 1:
-            record[:, 0:12] = counter.view(torch.uint8).view(B, 12)
-            record[:, 16:16 + 22 * mm] = matches
-            record[:, 16 + 22 * mm:16 + 26 * mm] = idx.view(torch.uint8).view(B, 4 * mm)
-            dist.all_gather_into_tensor(gathered, record)
+            feeds.pack_records(counter, matches, idx, record)
+            feeds.gather_records(record, gathered, dist)
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,94 @@
+"""The N > 1 path of bench.py on CPU: two ranks under gloo, each owning its own feeds, gathering fixed-size detection
+records.  The per-rank detections come from the CPU oracle here (no GPU in this container); on the GPU box the same
+pack / gather / unpack code carries the HIP path's outputs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+import oracle as O
+
+cfgs = cases.cfgs
+feeds = cases.vp.feeds if hasattr(cases.vp, "feeds") else None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _detections(rank, batch, cfg, mm):
+    from _vp_pkg import load
+    f = load().feeds
+    port = O.Port(threads=2)
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    counter = np.zeros((batch, 3), np.int32)
+    matches = np.zeros((batch, 22 * mm), np.uint8)
+    idx = np.zeros((batch, mm), np.int32)
+    for b in range(batch):
+        m, i, c = port.frame(cfg.synth(f.feed_seed(rank, b)), cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y,
+                             cfg.sampler_mode, cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+        counter[b] = c
+        matches[b, : 22 * len(m)] = np.frombuffer(m.tobytes(), np.uint8)
+        idx[b, : len(i)] = i.view(np.int32)
+    return counter, matches, idx
+
+
+def _worker(rank, world, port, batch, out_dir):
+    import sys
+    for p in (cases.ROOT, os.path.join(cases.ROOT, "tests"), os.path.join(cases.ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from _vp_pkg import load
+    f = load().feeds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, mm = cfgs.T_RGGB, 64
+    counter, matches, idx = _detections(rank, batch, cfg, mm)
+    record = torch.zeros((batch, f.record_bytes(mm)), dtype=torch.uint8)
+    f.pack_records(torch.from_numpy(counter), torch.from_numpy(matches), torch.from_numpy(idx), record)
+    gathered = torch.zeros((world, batch, f.record_bytes(mm)), dtype=torch.uint8)
+    f.gather_records(record, gathered, dist)
+    gc, gm, gi = f.unpack_records(gathered, mm)
+    # every rank sees every rank's detections, bit for bit
+    ok = True
+    for r in range(world):
+        c, m, i = _detections(r, batch, cfg, mm)
+        ok &= np.array_equal(gc[r].numpy(), c) and np.array_equal(gm[r].numpy(), m) and np.array_equal(gi[r].numpy(), i)
+    # elapsed-time reduction used by bench.py: MAX over ranks
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok &= float(t.item()) == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").close()
+
+
+def test_two_ranks_gather_detection_records(tmp_path):
+    world, batch = 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
+
+
+def test_record_layout_roundtrip():
+    from _vp_pkg import load
+    f = load().feeds
+    mm, B = 2000, 3
+    assert f.record_bytes(mm) % 16 == 0 and f.record_bytes(mm) >= 16 + 26 * mm
+    rng = np.random.default_rng(0)
+    counter = torch.from_numpy(rng.integers(0, 5000, (B, 3), dtype=np.int32))
+    matches = torch.from_numpy(rng.integers(0, 256, (B, 22 * mm), dtype=np.uint8))
+    idx = torch.from_numpy(rng.integers(0, 1 << 21, (B, mm), dtype=np.int32))
+    rec = f.pack_records(counter, matches, idx, torch.zeros((B, f.record_bytes(mm)), dtype=torch.uint8))
+    c, m, i = f.unpack_records(rec[None], mm)
+    assert torch.equal(c[0], counter) and torch.equal(m[0], matches) and torch.equal(i[0], idx)
+    assert len({f.feed_seed(r, b) for r in range(8) for b in range(64)}) == 8 * 64

@@ -4,7 +4,7 @@ Python here is plumbing for tests and the benchmark: `capi` binds the C ABI of l
 `hostlib` binds the GPU-free C++ host side (synthetic frames, geometry producer), `configs` holds the standard
 parameter sets.  The product is the HIP library and the C++ facade under host/.
 """
-from . import configs, hostlib  # noqa: F401
+from . import configs, feeds, hostlib  # noqa: F401
 
 
 def load_capi():

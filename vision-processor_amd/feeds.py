@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of the hot path: independent camera feeds, one (set of) feed(s) per rank, no data-path collective.
+
+The only exchange the path has is at the end of a step: every rank contributes one fixed-size detection record per frame
+(counter[3], the 22-byte match records, their pixel indices) and all ranks gather them.  The reference has
+no counterpart (one process per camera exchanging protobufs over UDP multicast, udpsocket.cpp:94-100); on one node the
+gather is a single RCCL all-gather of ~52 KB per frame, latency-bound.
+
+Device-agnostic torch code so the same functions run under `gloo` on CPU tensors in the tests."""
+from __future__ import annotations
+
+import torch
+
+MATCH_BYTES = 22
+HEADER_BYTES = 16  # counter[3] as int32 + 4 bytes padding
+
+
+def record_bytes(max_matches: int) -> int:
+    n = HEADER_BYTES + MATCH_BYTES * max_matches + 4 * max_matches
+    return n + (-n) % 16
+
+
+def feed_seed(rank: int, frame: int) -> int:
+    """Synthetic feed of rank `rank`, frame `frame`: distinct scenes for every (rank, frame)."""
+    return rank * 100000 + frame
+
+
+def pack_records(counter: torch.Tensor, matches: torch.Tensor, idx: torch.Tensor, record: torch.Tensor) -> torch.Tensor:
+    """counter (B,3) int32, matches (B, 22*max) uint8, idx (B, max) int32 -> record (B, record_bytes) uint8, in place."""
+    b = counter.shape[0]
+    mm = idx.shape[1]
+    record[:, 0:12] = counter.contiguous().view(torch.uint8).view(b, 12)
+    record[:, HEADER_BYTES:HEADER_BYTES + MATCH_BYTES * mm] = matches
+    record[:, HEADER_BYTES + MATCH_BYTES * mm:HEADER_BYTES + (MATCH_BYTES + 4) * mm] = idx.contiguous().view(torch.uint8).view(b, 4 * mm)
+    return record
+
+
+def unpack_records(gathered: torch.Tensor, max_matches: int):
+    """gathered (world, B, record_bytes) uint8 -> (counter (world,B,3) int32, matches (world,B,22*max) uint8, idx (world,B,max) int32)."""
+    w, b, _ = gathered.shape
+    mm = max_matches
+    counter = gathered[:, :, 0:12].contiguous().view(torch.int32).view(w, b, 3)
+    matches = gathered[:, :, HEADER_BYTES:HEADER_BYTES + MATCH_BYTES * mm].contiguous()
+    idx = gathered[:, :, HEADER_BYTES + MATCH_BYTES * mm:HEADER_BYTES + (MATCH_BYTES + 4) * mm].contiguous().view(torch.int32).view(w, b, mm)
+    return counter, matches, idx
+
+
+def gather_records(record: torch.Tensor, gathered: torch.Tensor, dist) -> torch.Tensor:
+    """All-gather the per-rank record block: one collective per step, equal counts on every rank."""
+    # flattened views: (world * B, bytes) <- (B, bytes); the gloo backend insists on the concatenated shape, RCCL accepts it too
+    dist.all_gather_into_tensor(gathered.view(-1, gathered.shape[-1]), record)
+    return gathered
