@@ -255,6 +255,31 @@ def test_full_size_properties(gpu, port):
     assert 60 <= len(strong) <= 200
 
 
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.T_RGGB], ids=lambda c: c.name)
+@pytest.mark.parametrize("o", [1, 2, 3, 4])
+def test_halo_strips_path(gpu, port, cfg, o):
+    """Single-pass SAT fed by compact halo strips (built standalone here, emitted by the resampling kernels inside vp_frame)."""
+    capi, ctx, torch = gpu
+    rng = np.random.default_rng(o)
+    B, h, w = 2, cfg.fh, cfg.fw
+    flat = rng.integers(0, 256, (B, h, w, 4), dtype=np.uint8)
+    flat[..., 3] = 255
+    d_flat = dev(torch, flat)
+    nbytes = ctx.halo_strip_bytes(w, h, o)
+    assert nbytes == 2 * (w // 64) * h * o * 4
+    d_strips = torch.full((B, nbytes // 4), 0x55AA55AA, dtype=torch.int32, device="cuda")
+    ctx.halo_strips(d_flat, w, h, o, B, d_strips)
+    d_sat = torch.zeros((B, h, w), dtype=torch.int32, device="cuda")
+    d_gd = torch.zeros((B, h, w), dtype=torch.float32, device="cuda")
+    ctx.graddot_sat_strips(d_flat, d_strips, w, h, o, B, capi.SAT_TILED, d_sat, d_gd)
+    ctx.sync()
+    for i in range(B):
+        g = port.graddot(flat[i], o)
+        assert np.array_equal(host(d_gd[i]), g)
+        assert np.array_equal(host(d_sat[i]), g.astype(np.int64).cumsum(0).cumsum(1).astype(np.int32))
+    assert ctx.halo_strip_bytes(w + 1, h, o) == 0 and ctx.halo_strip_bytes(w, h, 5) == 0
+
+
 def test_abi_memory_and_events(gpu):
     """The plain-pointer half of the ABI (no torch): vp_malloc / copies / memset / stage timers."""
     capi, _, torch = gpu

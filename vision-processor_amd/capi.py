@@ -195,6 +195,16 @@ class Context:
     def graddot_sat(self, flat, w, h, offset, batch, variant, sat, graddot_out=None, stream=0):
         self._ck(self.l.vp_graddot_sat(self.h, stream, _ptr(flat), int(w), int(h), int(offset), int(batch), int(variant), _ptr(sat), _ptr(graddot_out)))
 
+    def halo_strip_bytes(self, w, h, offset):
+        self.l.vp_halo_strip_bytes.restype = C.c_size_t
+        return int(self.l.vp_halo_strip_bytes(int(w), int(h), int(offset)))
+
+    def halo_strips(self, flat, w, h, offset, batch, strips, stream=0):
+        self._ck(self.l.vp_halo_strips(self.h, stream, _ptr(flat), int(w), int(h), int(offset), int(batch), _ptr(strips)))
+
+    def graddot_sat_strips(self, flat, strips, w, h, offset, batch, variant, sat, graddot_out=None, stream=0):
+        self._ck(self.l.vp_graddot_sat_strips(self.h, stream, _ptr(flat), _ptr(strips), int(w), int(h), int(offset), int(batch), int(variant), _ptr(sat), _ptr(graddot_out)))
+
     def blobcenter(self, sat, w, h, radius, batch, out, stream=0):
         self._ck(self.l.vp_blobcenter(self.h, stream, _ptr(sat), int(w), int(h), int(radius), int(batch), _ptr(out)))
 

@@ -29,7 +29,7 @@ struct VpContext {
 	int n_streams = 0;
 	bool own_streams = true;
 	hipStream_t streams[VP_MAX_STREAMS] = {};
-	VpWorkspace ws[3][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries; slot 2: coordinate map
+	VpWorkspace ws[4][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries; slot 2: coordinate map; slot 3: halo strips
 	unsigned char map_key[VP_MAX_STREAMS][96] = {}; // geometry the cached coordinate map of each stream was built for
 	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // generation tag of the single-pass SAT carry granules
 	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tickets handed out per frame queue by all earlier launches on this stream (mod 2^32)
@@ -111,6 +111,26 @@ static inline int vp_launch_ok(const char* what) {
 }
 
 static inline unsigned vp_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// Halo strips (include/vp_hip.h): per frame two arrays [tilesX][h][offset] of RGBA8 pixels; entry (b, y, k) of the first holds
+// flat[y][64 b - offset + k] (the pixels left of boundary b), of the second flat[y][64 b + k] (right of it).  b = 0 is unused.
+struct VpStrips {
+	uint32_t* base;       // nullptr: not in use
+	int tiles_x, h, o;
+	size_t frame_words;   // uint32 per frame = 2 * tiles_x * h * o
+	__host__ __device__ size_t left(int b, int y, int k) const { return ((size_t)b * h + y) * o + k; }
+	__host__ __device__ size_t right(int b, int y, int k) const { return ((size_t)(tiles_x + b) * h + y) * o + k; }
+};
+static inline bool vp_strips_supported(int w, int offset) { return w > 0 && (w % 64) == 0 && offset >= 1 && offset <= 4; }
+static inline VpStrips vp_make_strips(uint32_t* base, int w, int h, int offset) {
+	VpStrips s;
+	s.base = base;
+	s.tiles_x = w / 64;
+	s.h = h;
+	s.o = offset;
+	s.frame_words = (size_t)2 * s.tiles_x * h * offset;
+	return s;
+}
 
 // ---- device helpers ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ int vp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

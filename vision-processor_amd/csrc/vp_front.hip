@@ -91,12 +91,22 @@ extern "C" int vp_raw2quad4(VpContext* ctx, int stream, const uint8_t* raw, int 
 }
 
 // ---------------------------------------------------------------- resampling --------------------------------------
+// While writing a flat pixel, also drop it into the halo strips if it sits within `o` pixels of a 64-pixel tile boundary.
+__device__ __forceinline__ void emit_strip(const VpStrips& st, int frame, int gx, int gy, uint32_t px4) {
+	if(!st.base) return;
+	const int xm = gx & 63, b = gx >> 6;
+	uint32_t* f = st.base + (size_t)frame * st.frame_words;
+	if(xm >= 64 - st.o && b + 1 < st.tiles_x) f[st.left(b + 1, gy, xm - (64 - st.o))] = px4;
+	if(xm < st.o && b > 0) f[st.right(b, gy, xm)] = px4;
+}
+
 struct ResampleArgs {
 	VpCameraModel m;
 	float height, fs, ox, oy;
 	int qw, qh, fw, fh;
 	const uint8_t* pl[4]; // plane sources (unused when sampling the raw buffer)
 	size_t pl_bstride;
+	VpStrips strips;      // optional halo-strip output
 };
 
 // resampling.cl:29-47
@@ -238,6 +248,37 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
 	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
 	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * a.fw * a.fh + (size_t)gy * a.fw + gx] = px4;
+	emit_strip(a.strips, blockIdx.z, gx, gy, px4);
+}
+
+__global__ __launch_bounds__(256) void k_halo_strips(const uint32_t* __restrict__ flat, const VpStrips st, int w) {
+	// one thread per (boundary, row, side, k)
+	const int per_row = 2 * st.o;
+	const size_t total = (size_t)(st.tiles_x - 1) * st.h * per_row;
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if(i >= total) return;
+	const int e = (int)(i % per_row), y = (int)((i / per_row) % st.h), b = 1 + (int)(i / ((size_t)per_row * st.h));
+	const uint32_t* f = flat + (size_t)blockIdx.y * w * st.h;
+	uint32_t* out = st.base + (size_t)blockIdx.y * st.frame_words;
+	if(e < st.o) out[st.left(b, y, e)] = f[(size_t)y * w + 64 * b - st.o + e];
+	else out[st.right(b, y, e - st.o)] = f[(size_t)y * w + 64 * b + (e - st.o)];
+}
+
+extern "C" size_t vp_halo_strip_bytes(int w, int h, int offset) {
+	if(!vp_strips_supported(w, offset) || h <= 0) return 0;
+	return sizeof(uint32_t) * vp_make_strips(nullptr, w, h, offset).frame_words;
+}
+
+extern "C" int vp_halo_strips(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, uint32_t* strips) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(flat && strips && h > 0 && batch > 0 && batch <= 65535 && vp_strips_supported(w, offset), "vp_halo_strips: needs w %% 64 == 0 and 1 <= offset <= 4");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "halo strips");
+	const VpStrips st = vp_make_strips(strips, w, h, offset);
+	const size_t total = (size_t)(st.tiles_x - 1) * h * 2 * offset;
+	if(total == 0) return VP_OK;
+	k_halo_strips<<<dim3((unsigned)((total + 255) / 256), batch), 256, 0, ctx->streams[stream]>>>(reinterpret_cast<const uint32_t*>(flat), st, w);
+	return vp_launch_ok("halo strips");
 }
 
 // ---- coordinate map ---------------------------------------------------------------------------------------------
@@ -252,7 +293,7 @@ __global__ __launch_bounds__(256) void k_resample_map(float2* __restrict__ map, 
 
 template<int LAYOUT, int MODE>
 __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
-		int qw, int qh, int fw, int fh, size_t src_frame_bytes) {
+		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips) {
 	const int gx = blockIdx.x * 64 + threadIdx.x;
 	const int gy = blockIdx.y * 4 + threadIdx.y;
 	if(gx >= fw || gy >= fh) return;
@@ -283,6 +324,7 @@ __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restri
 	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
 	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
 	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * fw * fh + (size_t)gy * fw + gx] = px4;
+	emit_strip(strips, blockIdx.z, gx, gy, px4);
 }
 
 extern "C" int vp_resample_map(VpContext* ctx, int stream, const VpCameraModel* model, float max_robot_height, float field_scale, float off_x, float off_y,
@@ -300,12 +342,22 @@ extern "C" int vp_resample_map(VpContext* ctx, int stream, const VpCameraModel* 
 	a.qw = a.qh = 0;
 	a.fw = fw;
 	a.fh = fh;
+	a.strips = vp_make_strips(nullptr, 64, 1, 1);
 	k_resample_map<<<dim3(vp_div_up(fw, 64), vp_div_up(fh, 4)), dim3(64, 4), 0, ctx->streams[stream]>>>(reinterpret_cast<float2*>(map), a);
 	return vp_launch_ok("resampling map");
 }
 
+int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const float* map, int sampler_mode,
+		int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips);
+
 extern "C" int vp_resample_raw_mapped(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const float* map, int sampler_mode,
 		int fw, int fh, int batch, uint8_t* flat) {
+	VpStrips none = vp_make_strips(nullptr, 64, 1, 1);
+	return vp_resample_raw_mapped_impl(ctx, stream, raw, layout, qw, qh, map, sampler_mode, fw, fh, batch, flat, none);
+}
+
+int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const float* map, int sampler_mode,
+		int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(raw && map && flat && qw > 0 && qh > 0 && fw > 0 && fh > 0 && batch > 0 && batch <= 65535, "vp_resample_raw_mapped: bad arguments");
 	VP_REQUIRE(layout >= 0 && layout <= 2 && (sampler_mode == VP_SAMPLER_NEAREST || sampler_mode == VP_SAMPLER_BILINEAR_RTZ), "vp_resample_raw_mapped: bad layout/sampler mode");
@@ -316,7 +368,7 @@ extern "C" int vp_resample_raw_mapped(VpContext* ctx, int stream, const uint8_t*
 	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), batch), block(64, 4);
 	hipStream_t s = ctx->streams[stream];
 	const float2* m2 = reinterpret_cast<const float2*>(map);
-#define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes)
+#define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips)
 	if(sampler_mode == VP_SAMPLER_NEAREST) {
 		if(layout == VP_LAYOUT_RGGB) VP_RM(VP_LAYOUT_RGGB, VP_SAMPLER_NEAREST);
 		else if(layout == VP_LAYOUT_GRBG) VP_RM(VP_LAYOUT_GRBG, VP_SAMPLER_NEAREST);
@@ -332,7 +384,7 @@ extern "C" int vp_resample_raw_mapped(VpContext* ctx, int stream, const uint8_t*
 
 template<bool FROM_RAW>
 static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, const uint8_t* const* planes4, int layout, int qw, int qh, const VpCameraModel* model,
-		float height, float fs, float ox, float oy, int mode, int fw, int fh, int batch, uint8_t* flat, const char* name) {
+		float height, float fs, float ox, float oy, int mode, int fw, int fh, int batch, uint8_t* flat, const char* name, const VpStrips* strips = nullptr) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE((src || planes4) && flat && model, "%s: null pointer", name);
 	VP_REQUIRE(qw > 0 && qh > 0 && fw > 0 && fh > 0 && batch > 0 && batch <= 65535, "%s: bad shape", name);
@@ -352,6 +404,7 @@ static int resample_dispatch(VpContext* ctx, int stream, const uint8_t* src, con
 	a.fh = fh;
 	const size_t q = (size_t)qw * qh;
 	const size_t frame_bytes = FROM_RAW ? (layout == VP_LAYOUT_BGR ? 3 * q : 4 * q) : 4 * q;
+	a.strips = strips ? *strips : vp_make_strips(nullptr, 64, 1, 1);
 	for(int c = 0; c < 4; c++) a.pl[c] = FROM_RAW ? nullptr : (planes4 ? planes4[c] : src + c * q);
 	a.pl_bstride = planes4 ? 0 : 4 * q;
 	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), batch), block(64, 4);
@@ -380,6 +433,12 @@ extern "C" int vp_resample4(VpContext* ctx, int stream, const uint8_t* plane0, c
 	VP_REQUIRE(plane0 && plane1 && plane2 && (plane3 || layout == VP_LAYOUT_BGR), "vp_resample4: null plane");
 	const uint8_t* pl[4] = {plane0, plane1, plane2, plane3 ? plane3 : plane2};
 	return resample_dispatch<false>(ctx, stream, nullptr, pl, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, 1, flat, "resampling");
+}
+
+int vp_resample_impl(VpContext* ctx, int stream, const uint8_t* src, bool from_raw, int layout, int qw, int qh, const VpCameraModel* model,
+		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips) {
+	if(from_raw) return resample_dispatch<true>(ctx, stream, src, nullptr, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "raw2quad+resampling", &strips);
+	return resample_dispatch<false>(ctx, stream, src, nullptr, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "resampling", &strips);
 }
 
 extern "C" int vp_resample_raw(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const VpCameraModel* model,

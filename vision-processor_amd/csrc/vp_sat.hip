@@ -128,9 +128,9 @@ int vp_sat_twopass(VpContext* ctx, int stream, const void* in, bool fused, int w
 	return vp_launch_ok("sat column pass");
 }
 
-int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out);
+int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out, const uint32_t* strips);
 
-static int sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name) {
+static int sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name, const uint32_t* strips = nullptr) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(in && sat && w > 0 && h > 0 && batch > 0 && batch <= 65535 && offset >= 0, "%s: bad arguments", name);
 	VP_REQUIRE(variant == VP_SAT_TILED || variant == VP_SAT_TWOPASS, "%s: unknown SAT variant %d", name, variant);
@@ -138,7 +138,7 @@ static int sat_common(VpContext* ctx, int stream, const void* in, bool fused, in
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, name);
 	if(variant == VP_SAT_TWOPASS) return vp_sat_twopass(ctx, stream, in, fused, w, h, offset, batch, sat, gd);
-	return vp_sat_tiled(ctx, stream, in, fused, w, h, offset, batch, sat, gd);
+	return vp_sat_tiled(ctx, stream, in, fused, w, h, offset, batch, sat, gd, strips);
 }
 
 extern "C" int vp_sat(VpContext* ctx, int stream, const float* graddot, int w, int h, int batch, int variant, int32_t* sat) {
@@ -147,4 +147,9 @@ extern "C" int vp_sat(VpContext* ctx, int stream, const float* graddot, int w, i
 
 extern "C" int vp_graddot_sat(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, int variant, int32_t* sat, float* graddot_out) {
 	return sat_common(ctx, stream, flat, true, w, h, offset, batch, variant, sat, graddot_out, "gradientDot+sat");
+}
+
+extern "C" int vp_graddot_sat_strips(VpContext* ctx, int stream, const uint8_t* flat, const uint32_t* strips, int w, int h, int offset, int batch, int variant,
+		int32_t* sat, float* graddot_out) {
+	return sat_common(ctx, stream, flat, true, w, h, offset, batch, variant, sat, graddot_out, "gradientDot+sat", strips);
 }

@@ -47,6 +47,7 @@ struct TiledArgs {
 	const uint32_t* order; // ticket -> (ti << 16 | tj): anti-diagonal order of the tile grid (a linear extension of the carry dependencies)
 	uint32_t* ctrl; // [0] abort word, [16 + 16 f] ticket counter of frame f (monotonic across launches, one 64-B line each)
 	int* host_flag; // pinned, device-mapped
+	VpStrips strips; // optional halo strips (base == nullptr: halo columns are read from flat)
 	int debug;      // timing experiments only (VP_SAT_DEBUG env): bit0 = skip look-back waits (WRONG results)
 };
 
@@ -92,14 +93,15 @@ __device__ __forceinline__ bool aborted(const TiledArgs& a) {
 // Exclusive carry of this lane's element along one chain: walk the predecessors (nearest first), adding aggregates
 // until an inclusive granule is met.  `g` points at THIS tile's granule for this lane, predecessors are `stride`
 // granules apart.  Wave-uniform control flow; returns false on timeout / abort.
+template<bool DBG = true>
 __device__ __forceinline__ bool lookback(const u64* g, long stride, int npred, const TiledArgs& a, int& carry, bool active = true) {
 	constexpr int WIN = 4; // predecessor granules kept in flight per round
 	int acc = 0;
 	bool done = !active; // lanes beyond the vector length ride along
 	carry = 0;
-	if(a.debug & 1) return true;
+	if(DBG && (a.debug & 1)) return true;
 	unsigned n_win = 0, n_repoll = 0;
-	const bool stats = (a.debug & 4) && (threadIdx.x & 63) == 0;
+	const bool stats = DBG && (a.debug & 4) && (threadIdx.x & 63) == 0;
 	for(int k0 = 1; k0 <= npred; k0 += WIN) {
 		n_win++;
 		u64 v[WIN];
@@ -158,7 +160,7 @@ __device__ __forceinline__ bool early_resolve(u64 pre0, u64 pre1, int npred, con
 	const bool inc0 = r0 && (t0 & 3u) == ST_INC;
 	const bool inc1 = npred >= 2 && (t1 >> 2) == a.epoch && (t1 & 3u) == ST_INC;
 	carry = (int)(uint32_t)pre0 + (inc0 ? 0 : (int)(uint32_t)pre1);
-	return __all(inc0 || (r0 && inc1)) && !(a.debug & 32);
+	return __all(inc0 || (r0 && inc1));
 }
 
 template<int MODE>
@@ -402,19 +404,25 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 //     look-back polls are issued, and written to LDS at the top of the next iteration;
 //   * sub-segment totals T16 alias the (dead) raw tile, so LDS stays <= 37.3 KB per workgroup (4 workgroups per CU).
 // LDS image of a tile: raw[rows][72] dwords = [4 - O pad | O halo | 64 interior | O halo | pad], rows = 64 + 2 O.
-template<int O>
+// DBG: carries the phase stamps / ablation switches of VP_SAT_DEBUG; the shipped instantiation (DBG = false) has none of them
+// (they cost registers: with the 128-VGPR budget of 4 waves per SIMD any spill puts scratch traffic on the same vmcnt queue as
+// the tile prefetch and drains it).
+template<int O, bool DBG>
 __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
 	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
 	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
 	constexpr int NI = (ROWS + 15) / 16;           // interior: 16 lanes x 16 B per row, 16 rows per pass
 	constexpr int NHAL = (ROWS * 2 * O + 255) / 256; // halo dwords per thread
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// O <= 2: raw 19.6 KB + S 16 KB + T16 4 KB + carries = 40 608 B <= 160 KB / 4, so T16 gets storage of its own and two of the
+	// five barriers per tile disappear; O = 3, 4: T16 aliases the raw tile (dead after phase B) behind an extra barrier.
+	constexpr bool ALIAS = O > 2;
 	uint32_t* raw = reinterpret_cast<uint32_t*>(smem);
-	int* T16 = reinterpret_cast<int*>(smem); // [16][64] column totals of the 4-row sub-segments; aliases raw (dead after phase B)
 	int* S = reinterpret_cast<int*>(raw + ROWS * PITCH);
 	int* Av = S + TH * TW;
 	int* Bv = Av + TW;
-	int* misc = Bv + TH; // [0] first ticket, [1] K, [2] Q, [3] next ticket
+	int* misc = Bv + TH; // [0] first ticket, [1] K, [2] Q, [3] next ticket, [4] wave slot
+	int* T16 = ALIAS ? reinterpret_cast<int*>(smem) : misc + 8; // [16][64] column totals of the 4-row sub-segments
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int w = a.w, h = a.h;
@@ -425,7 +433,8 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 	const uint32_t* flat = in + frame;
 	int32_t* out = sat + frame;
 	const bool loader = tid == 3 * 64;
-	const bool abl_gran = a.debug & 64, abl_store = a.debug & 128, abl_load = a.debug & 256, abl_comp = a.debug & 512;
+	const int dbg = DBG ? a.debug : 0;
+	const bool abl_gran = dbg & 64, abl_store = dbg & 128, abl_load = dbg & 256, abl_comp = dbg & 512;
 
 	uint32_t pending = 0;
 	if(loader) {
@@ -437,9 +446,9 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 	__syncthreads();
 	int rem = misc[0];
 	if(rem < 0 || rem >= perFrame) return;
-	if(a.debug & 1024) { // experiment: stagger co-resident workgroups so they do not convoy through the same phase together
+	if(dbg & 1024) { // experiment: stagger co-resident workgroups so they do not convoy through the same phase together
 		const int slot = misc[4];
-		for(int i = 0; i < slot * (a.debug >> 12); i++) __builtin_amdgcn_s_sleep(16);
+		for(int i = 0; i < slot * (dbg >> 12); i++) __builtin_amdgcn_s_sleep(16);
 	}
 
 	// ---- register image of the next tile -------------------------------------------------------------------------------
@@ -450,7 +459,21 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 #define VP_PF_LOAD(P, X0, Y0) (*reinterpret_cast<const uint4*>(flat + (size_t)vp_clampi((Y0) - O + VP_PF_ROW(P), 0, h - 1) * w + (X0) + 4 * c4))
 #define VP_HALO_E(J) (min(tid + 256 * (J), ROWS * 2 * O - 1))
 #define VP_HALO_GX(J, X0) ((VP_HALO_E(J) % (2 * O)) < O ? (X0) - O + (VP_HALO_E(J) % (2 * O)) : (X0) + TW + (VP_HALO_E(J) % (2 * O)) - O)
-#define VP_HALO_LOAD(J, X0, Y0) (flat[(size_t)vp_clampi((Y0) - O + VP_HALO_E(J) / (2 * O), 0, h - 1) * w + vp_clampi(VP_HALO_GX(J, X0), 0, w - 1)])
+	// halo element J of the tile at (X0, Y0): from the compact strips when they exist and the neighbour tile does (interior
+	// boundary), else straight from flat with clamp-to-edge (image border: the line is the tile's own)
+	const uint32_t* sbase = a.strips.base ? a.strips.base + (size_t)f * a.strips.frame_words : nullptr;
+	auto halo_load = [&](int e, int X0, int Y0) -> uint32_t {
+		const int r = e / (2 * O), k = e % (2 * O);
+		const int gy = vp_clampi(Y0 - O + r, 0, h - 1);
+		const int tjx = X0 >> 6;
+		if(sbase) {
+			if(k < O && tjx > 0) return sbase[a.strips.left(tjx, gy, k)];
+			if(k >= O && tjx + 1 < a.tilesX) return sbase[a.strips.right(tjx + 1, gy, k - O)];
+		}
+		const int gx = k < O ? X0 - O + k : X0 + TW + (k - O);
+		return flat[(size_t)gy * w + vp_clampi(gx, 0, w - 1)];
+	};
+#define VP_HALO_LOAD(J, X0, Y0) halo_load(VP_HALO_E(J), X0, Y0)
 #define VP_PREFETCH(X0, Y0)                            \
 	do {                                                 \
 		pv0 = VP_PF_LOAD(0, X0, Y0);                     \
@@ -458,9 +481,11 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 		pv2 = VP_PF_LOAD(2, X0, Y0);                     \
 		pv3 = VP_PF_LOAD(3, X0, Y0);                     \
 		if(NI > 4) pv4 = VP_PF_LOAD(4, X0, Y0);          \
+		if(!(dbg & 2048)) {                              \
 		hv0 = VP_HALO_LOAD(0, X0, Y0);                   \
 		if(NHAL > 1) hv1 = VP_HALO_LOAD(1, X0, Y0);      \
 		if(NHAL > 2) hv2 = VP_HALO_LOAD(2, X0, Y0);      \
+		}                                                \
 	} while(0)
 #define VP_COMMIT_ROW(P, V)                                                                                       \
 	do {                                                                                                            \
@@ -481,7 +506,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 	}
 
 	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	const bool stamp = (a.debug & 8) && lane == 0 && (wv == 0 || wv == 3);
+	const bool stamp = DBG && (a.debug & 8) && lane == 0 && (wv == 0 || wv == 3);
 	for(;;) {
 		const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		const uint32_t tcur = a.order[__builtin_amdgcn_readfirstlane(rem)];
@@ -525,7 +550,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 		// ---- B: 4 pixels per lane; lane = 16 q + m: columns 4m..4m+3, rows 16 wv + 4 q + it ---------------------------
 		const int m = lane & 15, q = lane >> 4;
 		int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
-#pragma unroll 2
+#pragma unroll 1
 		for(int it = 0; it < (abl_comp ? 0 : 4); it++) {
 			const int r = 16 * wv + 4 * q + it;
 			const uint32_t* c = raw + (r + O) * PITCH + 4 + 4 * m;
@@ -555,7 +580,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			*reinterpret_cast<int4*>(S + r * TW + 4 * m) = make_int4(run0, run1, run2, run3);
 		}
 		const unsigned long long tsb1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		lds_barrier(); // every wave is done with raw
+		if(ALIAS) lds_barrier(); // every wave is done with raw before T16 overwrites it
 		const unsigned long long tsb2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		*reinterpret_cast<int4*>(T16 + (4 * wv + q) * TW + 4 * m) = make_int4(run0, run1, run2, run3);
 		const unsigned long long tsb3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -571,7 +596,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			int carry = 0;
 			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) {
 				st_granule(g, a.epoch, ST_AGG, pc);
-				lookback(g, (long)a.tilesX * TW, ti, a, carry);
+				lookback<DBG>(g, (long)a.tilesX * TW, ti, a, carry);
 			}
 			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pc);
 			Av[lane] = carry;
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			int carry = 0;
 			if(!abl_gran && tj > 0 && !early_resolve(pre0, pre1, tj, a, carry)) {
 				st_granule(g, a.epoch, ST_AGG, pr);
-				lookback(g, TH, tj, a, carry);
+				lookback<DBG>(g, TH, tj, a, carry);
 			}
 			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pr);
 			Bv[lane] = carry;
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			}
 		} else if(wv == 2) { // corner chain
 			int carry = 0;
-			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback(a.K + tile, a.tilesX, ti, a, carry);
+			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback<DBG>(a.K + tile, a.tilesX, ti, a, carry);
 			if(lane == 0) misc[1] = carry;
 		}
 		const unsigned long long ts3a = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -633,7 +658,9 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 		}
 		if(!more) break;
 		rem = next;
-		lds_barrier(); // T16 (aliasing raw), S, Av, Bv, misc of this tile are dead only now
+		// No barrier here unless T16 aliases raw: the next commit only writes raw (last read before the barrier that follows
+		// phase B), and S / T16 / Av / Bv / misc are rewritten only behind the next tile's own barriers.
+		if(ALIAS) lds_barrier();
 	}
 	if(stamp) {
 		unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.ctrl + 16 + 16 * a.batch) + (wv == 3 ? 8 : 0);
@@ -653,7 +680,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 
 int vp_check_timeout(VpContext* ctx, int stream);
 
-int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out) {
+int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out, const uint32_t* strips) {
 	hipStream_t s = ctx->streams[stream];
 	const int o = fused ? offset : 0;
 	VP_REQUIRE(o <= 32, "VP_SAT_TILED: gradient offset %d > 32 is not supported (LDS halo)", o);
@@ -743,6 +770,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	VP_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dflag), ctx->host_flag[stream], 0));
 	a.host_flag = dflag;
 	a.debug = getenv("VP_SAT_DEBUG") ? atoi(getenv("VP_SAT_DEBUG")) : 0;
+	a.strips = vp_make_strips((fused && strips && vp_strips_supported(w, o)) ? const_cast<uint32_t*>(strips) : nullptr, vp_strips_supported(w, o) ? w : 64, h, o >= 1 ? o : 1);
 
 	// persistent grid: P workgroups per frame queue; every workgroup overshoots its queue by exactly two tickets
 	const int perFrame = a.tilesX * a.tilesY;
@@ -755,12 +783,18 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	const bool fast = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
 			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0) && !(a.debug & 16);
 	if(fast) {
-		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8);
+		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8 + (o <= 2 ? 16 * TW : 0));
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
-		if(o == 1) k_sat_fast<1><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
-		else if(o == 2) k_sat_fast<2><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
-		else if(o == 3) k_sat_fast<3><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
-		else k_sat_fast<4><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a);
+#define VP_FAST(OO) \
+		do { \
+			if(a.debug) k_sat_fast<OO, true><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a); \
+			else k_sat_fast<OO, false><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a); \
+		} while(0)
+		if(o == 1) VP_FAST(1);
+		else if(o == 2) VP_FAST(2);
+		else if(o == 3) VP_FAST(3);
+		else VP_FAST(4);
+#undef VP_FAST
 	} else {
 #define VP_TILED_LAUNCH(M) \
 	do { \
