@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (one launch group)")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (one launch group)")
     ap.add_argument("--workload", default="cfg2_2048x1536_rggb")
     ap.add_argument("--sat", default="tiled", choices=["tiled", "twopass"])
     ap.add_argument("--order", default="raster", choices=["raster", "atomic"])
