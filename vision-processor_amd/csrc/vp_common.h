@@ -133,7 +133,7 @@ static inline VpStrips vp_make_strips(uint32_t* base, int w, int h, int offset) 
 }
 
 // ---- device helpers ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ int vp_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int vp_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); } // one v_med3_i32
 
 // inclusive wave-64 prefix sum (wrapping int32)
 __device__ __forceinline__ int vp_wave_scan_incl(int v) {

@@ -184,10 +184,6 @@ __device__ __forceinline__ Axis axis_lin(float u, int n) {
 	r.i1 = vp_clampi((int)fu + 1, 0, n - 1);
 	return r;
 }
-__device__ __forceinline__ float win_byte(uint2 w, int k) { // byte k (0..7) of the 8-byte window
-	const unsigned long long v = ((unsigned long long)w.y << 32) | w.x;
-	return (float)(uint32_t)((v >> (8 * k)) & 0xFF);
-}
 // same evaluation order as sample<>(): w00*t00 + w10*t10 + w01*t01 + w11*t11, truncated
 __device__ __forceinline__ uint32_t bilin(float t00, float t10, float t01, float t11, float a, float b) {
 	const float oma = 1.0f - a, omb = 1.0f - b;
@@ -198,20 +194,53 @@ __device__ __forceinline__ uint32_t bilin(float t00, float t10, float t01, float
 	t = t + w11 * t11;
 	return (uint32_t)t;
 }
-// p[0..3]: positional channels (even row/even col, even/odd, odd/even, odd/odd) sampled with BILINEAR_RTZ
-__device__ __forceinline__ void sample_bayer4(const uint8_t* __restrict__ raw, float px, float py, int qw, int qh, uint32_t p[4]) {
+// Frame-independent part of the four Bayer footprints of one flat pixel: window offsets, byte selectors, weights.
+struct Bayer4Geom {
+	uint32_t off_e0, off_e1, off_o0, off_o1; // byte offsets of the four 8-byte windows inside a sensor frame
+	uint32_t sa0, sa1, sb0, sb1;             // v_perm_b32 selectors of the two texels per axis (even / odd columns)
+	float xa, xb, ya, yb;                    // interpolation weights along x (even / odd columns) and y (even / odd rows)
+};
+__device__ __forceinline__ Bayer4Geom bayer4_geom(float px, float py, int qw, int qh) {
 	const Axis xa = axis_lin(px + 0.25f, qw), xb = axis_lin(px - 0.25f, qw);
 	const Axis ya = axis_lin(py + 0.25f, qh), yb = axis_lin(py - 0.25f, qh);
 	const int ibase = vp_clampi(min(xa.i0, xb.i0), 0, qw - 4);
-	const size_t row = 2 * (size_t)qw;
-	const uint8_t* base = raw + 2 * (size_t)ibase;
-	const uint2 e0 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * ya.i0) * row), e1 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * ya.i1) * row);
-	const uint2 o0 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * yb.i0 + 1) * row), o1 = *reinterpret_cast<const uint2_a2*>(base + (size_t)(2 * yb.i1 + 1) * row);
-	const int a0 = 2 * (xa.i0 - ibase), a1 = 2 * (xa.i1 - ibase), b0 = 2 * (xb.i0 - ibase) + 1, b1 = 2 * (xb.i1 - ibase) + 1;
-	p[0] = bilin(win_byte(e0, a0), win_byte(e0, a1), win_byte(e1, a0), win_byte(e1, a1), xa.a, ya.a);
-	p[1] = bilin(win_byte(e0, b0), win_byte(e0, b1), win_byte(e1, b0), win_byte(e1, b1), xb.a, ya.a);
-	p[2] = bilin(win_byte(o0, a0), win_byte(o0, a1), win_byte(o1, a0), win_byte(o1, a1), xa.a, yb.a);
-	p[3] = bilin(win_byte(o0, b0), win_byte(o0, b1), win_byte(o1, b0), win_byte(o1, b1), xb.a, yb.a);
+	// 32-bit offsets from the (wave-uniform) frame base: one sensor frame is far below 4 GiB
+	const uint32_t row = 2u * (uint32_t)qw, col = 2u * (uint32_t)ibase;
+	Bayer4Geom g;
+	g.off_e0 = (uint32_t)(2 * ya.i0) * row + col;
+	g.off_e1 = (uint32_t)(2 * ya.i1) * row + col;
+	g.off_o0 = (uint32_t)(2 * yb.i0 + 1) * row + col;
+	g.off_o1 = (uint32_t)(2 * yb.i1 + 1) * row + col;
+	g.sa0 = 0x0c0c0c00u | (uint32_t)(2 * (xa.i0 - ibase));
+	g.sa1 = 0x0c0c0c00u | (uint32_t)(2 * (xa.i1 - ibase));
+	g.sb0 = 0x0c0c0c00u | (uint32_t)(2 * (xb.i0 - ibase) + 1);
+	g.sb1 = 0x0c0c0c00u | (uint32_t)(2 * (xb.i1 - ibase) + 1);
+	g.xa = xa.a;
+	g.xb = xb.a;
+	g.ya = ya.a;
+	g.yb = yb.a;
+	return g;
+}
+__device__ __forceinline__ float win_sel(uint2 w, uint32_t sel) { return (float)__builtin_amdgcn_perm(w.y, w.x, sel); }
+// p[0..3]: positional channels (even row/even col, even/odd, odd/even, odd/odd) of one frame, BILINEAR_RTZ
+__device__ __forceinline__ void bayer4_combine(const uint2 e0, const uint2 e1, const uint2 o0, const uint2 o1, const Bayer4Geom& g, uint32_t p[4]);
+__device__ __forceinline__ void bayer4_eval(const uint8_t* __restrict__ raw, const Bayer4Geom& g, uint32_t p[4]) {
+	const uint2 e0 = *reinterpret_cast<const uint2_a2*>(raw + g.off_e0), e1 = *reinterpret_cast<const uint2_a2*>(raw + g.off_e1);
+	const uint2 o0 = *reinterpret_cast<const uint2_a2*>(raw + g.off_o0), o1 = *reinterpret_cast<const uint2_a2*>(raw + g.off_o1);
+	bayer4_combine(e0, e1, o0, o1, g, p);
+}
+__device__ __forceinline__ void bayer4_combine(const uint2 e0, const uint2 e1, const uint2 o0, const uint2 o1, const Bayer4Geom& g, uint32_t p[4]) {
+	p[0] = bilin(win_sel(e0, g.sa0), win_sel(e0, g.sa1), win_sel(e1, g.sa0), win_sel(e1, g.sa1), g.xa, g.ya);
+	p[1] = bilin(win_sel(e0, g.sb0), win_sel(e0, g.sb1), win_sel(e1, g.sb0), win_sel(e1, g.sb1), g.xb, g.ya);
+	p[2] = bilin(win_sel(o0, g.sa0), win_sel(o0, g.sa1), win_sel(o1, g.sa0), win_sel(o1, g.sa1), g.xa, g.yb);
+	p[3] = bilin(win_sel(o0, g.sb0), win_sel(o0, g.sb1), win_sel(o1, g.sb0), win_sel(o1, g.sb1), g.xb, g.yb);
+}
+__device__ __forceinline__ void sample_bayer4(const uint8_t* __restrict__ raw, float px, float py, int qw, int qh, uint32_t p[4]) {
+	bayer4_eval(raw, bayer4_geom(px, py, qw, qh), p);
+}
+__device__ __forceinline__ uint32_t drgb_pack(uint32_t r, uint32_t g, uint32_t b) { // resampling.cl:86-91
+	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
+	return min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
 }
 
 template<int LAYOUT, int MODE, bool FROM_RAW>
@@ -291,40 +320,131 @@ __global__ __launch_bounds__(256) void k_resample_map(float2* __restrict__ map, 
 	map[(size_t)gy * a.fw + gx] = make_float2(px, py);
 }
 
+// FPT frames of the batch per thread: the coordinate and everything derived from it (tap offsets, selectors, weights) are
+// computed once and reused, so the 8 B/px map is read once per FPT frames instead of once per frame.
+constexpr int RESAMPLE_FPT = 8;
+
+// The 256 pixels of a workgroup (64 x 4 of flat) need only about a kilobyte of distinct sensor bytes per frame, yet every
+// lane fetching its own four 8-byte windows keeps the texture addresser busy 85 % of the kernel (~36 TA cycles per unaligned
+// wave load).  So the workgroup finds the bounding box of its windows once (frame independent), then per frame stages that box
+// in LDS with ONE coalesced dword load per thread (double buffered, one barrier per frame) and reads the windows from LDS.
+// Boxes too large for the stage (exotic geometries) take the direct path; results are identical either way.
+constexpr int STAGE_DW = 1024; // dwords per stage buffer
+
 template<int LAYOUT, int MODE>
 __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
-		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips) {
+		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
+	__shared__ uint32_t stage[2][STAGE_DW + 4];
+	__shared__ int red[4][4];
 	const int gx = blockIdx.x * 64 + threadIdx.x;
 	const int gy = blockIdx.y * 4 + threadIdx.y;
-	if(gx >= fw || gy >= fh) return;
-	const float2 pos = map[(size_t)gy * fw + gx];
+	const bool valid = gx < fw && gy < fh;
+	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
 	const float px = pos.x, py = pos.y;
-	Src s;
-	s.raw = raw + (size_t)blockIdx.z * src_frame_bytes;
-	s.p[0] = s.p[1] = s.p[2] = s.p[3] = nullptr;
-	uint32_t r, g, b;
-	if(LAYOUT == VP_LAYOUT_BGR) {
-		r = sample<LAYOUT, MODE, true>(s, 2, px, py, qw, qh);
-		g = sample<LAYOUT, MODE, true>(s, 1, px, py, qw, qh);
-		b = sample<LAYOUT, MODE, true>(s, 0, px, py, qw, qh);
-	} else if(MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
-		uint32_t p[4];
-		sample_bayer4(s.raw, px, py, qw, qh, p);
-		if(LAYOUT == VP_LAYOUT_RGGB) { r = p[0]; g = p[1] / 2 + p[2] / 2; b = p[3]; }
-		else { r = p[1]; g = p[0] / 2 + p[3] / 2; b = p[2]; }
-	} else if(LAYOUT == VP_LAYOUT_RGGB) {
-		r = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh);
-		g = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh) / 2;
-		b = sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh);
-	} else {
-		r = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh);
-		g = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh) / 2;
-		b = sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh);
+	const int f0 = blockIdx.z * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
+	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)min(gy, fh - 1) * fw + min(gx, fw - 1);
+	const size_t npx = (size_t)fw * fh;
+	if(LAYOUT != VP_LAYOUT_BGR && MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
+		const Bayer4Geom g = bayer4_geom(px, py, qw, qh);
+		const uint32_t rowb = 2u * (uint32_t)qw;
+		// bounding box of this workgroup's windows: byte columns [cmin, cmax), sensor rows [rmin, rmax]
+		const int c_lo = (int)(g.off_e0 % rowb);
+		const int re0 = (int)(g.off_e0 / rowb), re1 = (int)(g.off_e1 / rowb), ro0 = (int)(g.off_o0 / rowb), ro1 = (int)(g.off_o1 / rowb);
+		int cmin = c_lo, cmax = c_lo + 8, rmin = min(min(re0, re1), min(ro0, ro1)), rmax = max(max(re0, re1), max(ro0, ro1));
+#pragma unroll
+		for(int d = 32; d > 0; d >>= 1) {
+			cmin = min(cmin, __shfl_xor(cmin, d, 64));
+			cmax = max(cmax, __shfl_xor(cmax, d, 64));
+			rmin = min(rmin, __shfl_xor(rmin, d, 64));
+			rmax = max(rmax, __shfl_xor(rmax, d, 64));
+		}
+		const int tid = threadIdx.y * 64 + threadIdx.x;
+		if(threadIdx.x == 0) {
+			red[threadIdx.y][0] = cmin;
+			red[threadIdx.y][1] = cmax;
+			red[threadIdx.y][2] = rmin;
+			red[threadIdx.y][3] = rmax;
+		}
+		__syncthreads();
+		cmin = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+		cmax = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+		rmin = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+		rmax = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+		const int c0 = cmin & ~3, wdw = (cmax - c0 + 3) >> 2, hr = rmax - rmin + 1, ndw = wdw * hr;
+		// (a single frame per thread cannot hide the stage's round trip behind the previous frame's arithmetic: direct path)
+		const bool staged = f1 - f0 >= 2 && ndw <= STAGE_DW && (qw & 1) == 0 && ((reinterpret_cast<uintptr_t>(raw) | src_frame_bytes) & 3) == 0;
+		if(staged) { // workgroup-uniform
+			// which dwords of the box this thread fetches (<= 4), and where its own windows start inside the box
+			uint32_t goff[STAGE_DW / 256];
+#pragma unroll
+			for(int k = 0; k < STAGE_DW / 256; k++) {
+				const int i = tid + 256 * k, r = i / wdw, c = i - r * wdw;
+				goff[k] = (uint32_t)(rmin + r) * rowb + (uint32_t)c0 + 4u * (uint32_t)c;
+			}
+			const int wcol = (c_lo - c0) >> 2;
+			const uint32_t sh = (uint32_t)(c_lo - c0) & 3u; // 0 or 2
+			const int ie0 = (re0 - rmin) * wdw + wcol, ie1 = (re1 - rmin) * wdw + wcol, io0 = (ro0 - rmin) * wdw + wcol, io1 = (ro1 - rmin) * wdw + wcol;
+			uint32_t pre[STAGE_DW / 256];
+			const uint8_t* fr = raw + (size_t)f0 * src_frame_bytes;
+#pragma unroll
+			for(int k = 0; k < STAGE_DW / 256; k++) pre[k] = (tid + 256 * k < ndw) ? *reinterpret_cast<const uint32_t*>(fr + goff[k]) : 0u;
+			int buf = 0;
+			for(int f = f0; f < f1; f++, buf ^= 1) {
+#pragma unroll
+				for(int k = 0; k < STAGE_DW / 256; k++)
+					if(tid + 256 * k < ndw) stage[buf][tid + 256 * k] = pre[k];
+				__syncthreads();
+				if(f + 1 < f1) { // next frame's box -> registers while this one is consumed
+					fr = raw + (size_t)(f + 1) * src_frame_bytes;
+#pragma unroll
+					for(int k = 0; k < STAGE_DW / 256; k++) pre[k] = (tid + 256 * k < ndw) ? *reinterpret_cast<const uint32_t*>(fr + goff[k]) : 0u;
+				}
+				const uint32_t* st = stage[buf];
+				auto window = [&](int i) { return make_uint2(__builtin_amdgcn_alignbyte(st[i + 1], st[i], sh), __builtin_amdgcn_alignbyte(st[i + 2], st[i + 1], sh)); };
+				uint32_t p[4];
+				bayer4_combine(window(ie0), window(ie1), window(io0), window(io1), g, p);
+				const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+				if(valid) {
+					out[(size_t)f * npx] = px4;
+					emit_strip(strips, f, gx, gy, px4);
+				}
+			}
+			return;
+		}
+		if(!valid) return;
+#pragma unroll 2
+		for(int f = f0; f < f1; f++) {
+			uint32_t p[4];
+			bayer4_eval(raw + (size_t)f * src_frame_bytes, g, p);
+			const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+			out[(size_t)f * npx] = px4;
+			emit_strip(strips, f, gx, gy, px4);
+		}
+		return;
 	}
-	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
-	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
-	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * fw * fh + (size_t)gy * fw + gx] = px4;
-	emit_strip(strips, blockIdx.z, gx, gy, px4);
+	if(!valid) return;
+	for(int f = f0; f < f1; f++) {
+		Src s;
+		s.raw = raw + (size_t)f * src_frame_bytes;
+		s.p[0] = s.p[1] = s.p[2] = s.p[3] = nullptr;
+		uint32_t r, g, b;
+		if(LAYOUT == VP_LAYOUT_BGR) {
+			r = sample<LAYOUT, MODE, true>(s, 2, px, py, qw, qh);
+			g = sample<LAYOUT, MODE, true>(s, 1, px, py, qw, qh);
+			b = sample<LAYOUT, MODE, true>(s, 0, px, py, qw, qh);
+		} else if(LAYOUT == VP_LAYOUT_RGGB) {
+			r = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh);
+			g = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh) / 2;
+			b = sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh);
+		} else {
+			r = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh);
+			g = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh) / 2;
+			b = sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh);
+		}
+		const uint32_t px4 = drgb_pack(r, g, b);
+		out[(size_t)f * npx] = px4;
+		emit_strip(strips, f, gx, gy, px4);
+	}
 }
 
 extern "C" int vp_resample_map(VpContext* ctx, int stream, const VpCameraModel* model, float max_robot_height, float field_scale, float off_x, float off_y,
@@ -365,10 +485,10 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, "raw2quad+resampling");
 	const size_t q = (size_t)qw * qh, frame_bytes = layout == VP_LAYOUT_BGR ? 3 * q : 4 * q;
-	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), batch), block(64, 4);
+	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT)), block(64, 4);
 	hipStream_t s = ctx->streams[stream];
 	const float2* m2 = reinterpret_cast<const float2*>(map);
-#define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips)
+#define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch)
 	if(sampler_mode == VP_SAMPLER_NEAREST) {
 		if(layout == VP_LAYOUT_RGGB) VP_RM(VP_LAYOUT_RGGB, VP_SAMPLER_NEAREST);
 		else if(layout == VP_LAYOUT_GRBG) VP_RM(VP_LAYOUT_GRBG, VP_SAMPLER_NEAREST);
