@@ -135,6 +135,14 @@ static inline VpStrips vp_make_strips(uint32_t* base, int w, int h, int offset) 
 // ---- device helpers ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ int vp_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); } // one v_med3_i32
 
+// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): blocks are dealt round-robin over the 8 XCDs, each with
+// a private L2; this hands every XCD a CONTIGUOUS range of logical block ids so that neighbouring tiles share an L2 (halo
+// re-reads become L2 hits).  Speed only: any placement gives the same results.
+__device__ __forceinline__ unsigned vp_xcd_remap(unsigned b, unsigned n) {
+	const unsigned q = n >> 3, r = n & 7u, xcd = b & 7u;
+	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 // inclusive wave-64 prefix sum (wrapping int32)
 __device__ __forceinline__ int vp_wave_scan_incl(int v) {
 	const int lane = threadIdx.x & 63;

@@ -336,12 +336,16 @@ __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restri
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
 	__shared__ uint32_t stage[2][STAGE_DW + 4];
 	__shared__ int red[4][4];
-	const int gx = blockIdx.x * 64 + threadIdx.x;
-	const int gy = blockIdx.y * 4 + threadIdx.y;
+	// 1-D grid, XCD-aware (vp_xcd_remap): consecutive logical ids walk along x, then y, then the frame group
+	const unsigned nbx = (unsigned)(fw + 63) / 64, nby = (unsigned)(fh + 3) / 4;
+	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
+	const unsigned bz = lb / (nbx * nby), brem = lb - bz * nbx * nby;
+	const int gx = (int)(brem % nbx) * 64 + threadIdx.x;
+	const int gy = (int)(brem / nbx) * 4 + threadIdx.y;
 	const bool valid = gx < fw && gy < fh;
 	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
 	const float px = pos.x, py = pos.y;
-	const int f0 = blockIdx.z * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
+	const int f0 = (int)bz * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
 	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)min(gy, fh - 1) * fw + min(gx, fw - 1);
 	const size_t npx = (size_t)fw * fh;
 	if(LAYOUT != VP_LAYOUT_BGR && MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
@@ -485,7 +489,7 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, "raw2quad+resampling");
 	const size_t q = (size_t)qw * qh, frame_bytes = layout == VP_LAYOUT_BGR ? 3 * q : 4 * q;
-	const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT)), block(64, 4);
+	const dim3 grid(vp_div_up(fw, 64) * vp_div_up(fh, 4) * vp_div_up(batch, RESAMPLE_FPT)), block(64, 4);
 	hipStream_t s = ctx->streams[stream];
 	const float2* m2 = reinterpret_cast<const float2*>(map);
 #define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch)

@@ -237,10 +237,14 @@ constexpr int FT_W = 64, FT_H = 32;
 // NE: region elements per thread held in registers so that ALL global loads are in flight before the first LDS store
 // (a plain load->store loop with run-time bounds is not unrolled and pays one memory round trip per iteration); NE = 0
 // selects that plain loop for very large radii.
-template<int NE>
+// RT: the circle radius as a compile-time constant (0 = run-time radius).  The kernel is VALU-bound on index arithmetic
+// (measured: SQ_ACTIVE_INST_VALU == kernel time); with RT fixed every tap offset, the region pitch and the divisions by it
+// fold into immediates.
+template<int NE, int RT>
 __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
-		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r, float thr) {
+		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r_arg, float thr) {
 	extern __shared__ __attribute__((aligned(16))) char smem_tail[];
+	const int r = RT > 0 ? RT : r_arg;
 	const int halo = r + 1;
 	const int RW = FT_W + 2 * halo, RH = FT_H + 2 * halo;
 	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - halo + rx)]
@@ -327,15 +331,21 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
 		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + 255) / 256;
 		const dim3 grid(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch);
-#define VP_CD(N) \
+#define VP_CD(N, R) \
 		do { \
-			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-			k_circle_detect<N><<<grid, 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
+			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+			k_circle_detect<N, R><<<grid, 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
 		} while(0)
-		if(per_thread <= 14) VP_CD(14);
-		else if(per_thread <= 20) VP_CD(20);
-		else if(per_thread <= 32) VP_CD(32);
-		else VP_CD(0);
+#define VP_CD_R(R) case R: VP_CD(((FT_W + 2 * (R + 1)) * (FT_H + 2 * (R + 1)) + 255) / 256, R); break
+		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale)): compile-time specialisations
+			VP_CD_R(3); VP_CD_R(4); VP_CD_R(5); VP_CD_R(6); VP_CD_R(7); VP_CD_R(8); VP_CD_R(9); VP_CD_R(10);
+		default:
+			if(per_thread <= 14) VP_CD(14, 0);
+			else if(per_thread <= 20) VP_CD(20, 0);
+			else if(per_thread <= 32) VP_CD(32, 0);
+			else VP_CD(0, 0);
+		}
+#undef VP_CD_R
 #undef VP_CD
 		VP_TRY(vp_launch_ok("circle+detect"));
 		k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
