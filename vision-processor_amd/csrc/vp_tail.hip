@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	const int halo = r + 1;
 	const int RW = FT_W + 2 * halo, RH = FT_H + 2 * halo;
 	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - halo + rx)]
-	float* bc = reinterpret_cast<float*>(region + RW * RH);   // (FT_H + 2) x (FT_W + 2)
 	const int z = blockIdx.z;
 	const size_t n = (size_t)w * h;
 	const int32_t* sat = sat_all + z * n;
@@ -278,19 +277,31 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 		}
 	}
 	__syncthreads();
+	// All four quadrant sums of satBlobCenter.cl:37-40 are ONE box-sum image sampled at four offsets:
+	//   Bx(u, v) = S(u+r-1, v+r-1) - S(u+r-1, v) - S(u, v+r-1) + S(u, v)        (every tap clamped on its own, as in the reference)
+	//   pp(x, y) = Bx(x+1, y+1),  nn = Bx(x-r, y-r),  pn = -Bx(x+1, y-r),  np = -Bx(x-r, y+1)
+	// so Bx is built once (4 LDS taps per entry) and blobCenter needs 4 reads instead of 16.  Bx covers u in
+	// [x0-1-r, x0+FT_W+1], v likewise (its origin coincides with the region's); wrapping int32 arithmetic, exact.
+	const int BXW = FT_W + r + 3, BXH = FT_H + r + 3;
+	int32_t* bx = reinterpret_cast<int32_t*>(region + RW * RH);
+	for(int e = tid; e < BXW * BXH; e += 256) {
+		const int by = e / BXW, bxx = e - by * BXW;
+		const uint32_t* c = region + by * RW + bxx;
+		bx[e] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
+	}
+	__syncthreads();
 	const float div = (float)(r * r);
 	constexpr int BW = FT_W + 2, BH = FT_H + 2;
+	float* bc = reinterpret_cast<float*>(region); // the blobCenter ring tile aliases the (now dead) SAT region
 	for(int e = tid; e < BW * BH; e += 256) {
-		const int by = e / BW, bx = e - by * BW;
-		// centre in image coordinates, clamped; region coordinates of the centre
-		const int cx = vp_clampi(x0 - 1 + bx, 0, w - 1) - (x0 - halo), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - halo);
-		const uint32_t* c = region + cy * RW + cx;
-#define RG(DX, DY) c[(DY) * RW + (DX)]
-		const float pp = (float)(int32_t)(RG(r, r) - RG(r, 1) - RG(1, r) + RG(1, 1));
-		const float pn = (float)(int32_t)(RG(r, -r) - RG(r, -1) - RG(1, -r) + RG(1, -1));
-		const float np = (float)(int32_t)(RG(-r, r) - RG(-r, 1) - RG(-1, r) + RG(-1, 1));
-		const float nn = (float)(int32_t)(RG(-r, -r) - RG(-r, -1) - RG(-1, -r) + RG(-1, -1));
-#undef RG
+		const int by = e / BW, bxx = e - by * BW;
+		// clamped centre, in Bx coordinates (origin x0-1-r, y0-1-r)
+		const int cx = vp_clampi(x0 - 1 + bxx, 0, w - 1) - (x0 - 1 - r), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - 1 - r);
+		const int32_t* c = bx + cy * BXW + cx;
+		const float pp = (float)c[BXW + 1];
+		const float nn = (float)c[-r * BXW - r];
+		const float pn = (float)(-c[-r * BXW + 1]);
+		const float np = (float)(-c[BXW - r]);
 		const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
 		bc[e] = (b < a ? b : a) / div;
 	}
@@ -327,7 +338,7 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 				w, h, min_score, radius, max_matches, 0);
 	} else {
 		const int halo = circle_radius + 1;
-		const size_t lds = sizeof(uint32_t) * (size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + sizeof(float) * (FT_W + 2) * (FT_H + 2);
+		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
 		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + 255) / 256;
 		const dim3 grid(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch);
