@@ -7,6 +7,8 @@
 // in the order of resampling.cl:29-47,53; this file is built with -ffp-contract=off and HIP's default correctly
 // rounded fp32 division.  Integer-linear sampling follows VpSamplerMode (frozen in oracle/ref_shim.c).
 #include "vp_common.h"
+#include <type_traits>
+#include <algorithm>
 
 // ---------------------------------------------------------------- raw2quad ----------------------------------------
 // Bayer, vector path: one thread de-interleaves four 2x2 cells = 8 B of each of two sensor rows into 4 B per plane.
@@ -238,9 +240,46 @@ __device__ __forceinline__ void bayer4_combine(const uint2 e0, const uint2 e1, c
 __device__ __forceinline__ void sample_bayer4(const uint8_t* __restrict__ raw, float px, float py, int qw, int qh, uint32_t p[4]) {
 	bayer4_eval(raw, bayer4_geom(px, py, qw, qh), p);
 }
-__device__ __forceinline__ uint32_t drgb_pack(uint32_t r, uint32_t g, uint32_t b) { // resampling.cl:86-91
-	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
-	return min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
+// delta-RGB in uint arithmetic (resampling.cl:86-91).  r, g, b are sampled bytes (<= 255), so every channel
+// (2c - d - e + 510) / 4 lies in [0, 255] and the reference's convert_uchar saturation never acts; written as
+// (3c + (510 - (r+g+b))) / 4 to share the sum.
+__device__ __forceinline__ uint32_t drgb_pack(uint32_t r, uint32_t g, uint32_t b) {
+	const uint32_t k = 510u - (r + g + b);
+	const uint32_t dr = (__umul24(r, 3u) + k) >> 2, dg = (__umul24(g, 3u) + k) >> 2, db = (__umul24(b, 3u) + k) >> 2;
+	return dr | (dg << 8) | (db << 16) | 0xFF000000u;
+}
+
+// Staged variant of the Bayer footprint: all texels of one sensor row that a flat pixel needs (two even-column and two
+// odd-column bytes) lie within 5 consecutive bytes starting at an even column, hence inside TWO aligned dwords.  One
+// v_perm_b32 per row gathers them, v_cvt_f32_ubyte0..3 converts them.
+struct Bayer4Stage {
+	int d0;                  // first dword (within the sensor row) of the two-dword window
+	int re0, re1, ro0, ro1;  // sensor rows of the four windows
+	uint32_t sel;            // perm selector: bytes [a.i0, a.i1, b.i0, b.i1]
+	float xa, xb, ya, yb;
+};
+__device__ __forceinline__ Bayer4Stage bayer4_stage(float px, float py, int qw, int qh) {
+	const Axis xa = axis_lin(px + 0.25f, qw), xb = axis_lin(px - 0.25f, qw);
+	const Axis ya = axis_lin(py + 0.25f, qh), yb = axis_lin(py - 0.25f, qh);
+	Bayer4Stage g;
+	// leftmost byte needed is column 2*min(i0) (even), rightmost at most 4 bytes further; keep both dwords inside the row
+	g.d0 = min((2 * min(xa.i0, xb.i0)) >> 2, (qw >> 1) - 2);
+	const int b0 = 4 * g.d0;
+	g.sel = (uint32_t)(2 * xa.i0 - b0) | ((uint32_t)(2 * xa.i1 - b0) << 8) | ((uint32_t)(2 * xb.i0 + 1 - b0) << 16) | ((uint32_t)(2 * xb.i1 + 1 - b0) << 24);
+	g.re0 = 2 * ya.i0;
+	g.re1 = 2 * ya.i1;
+	g.ro0 = 2 * yb.i0 + 1;
+	g.ro1 = 2 * yb.i1 + 1;
+	g.xa = xa.a;
+	g.xb = xb.a;
+	g.ya = ya.a;
+	g.yb = yb.a;
+	return g;
+}
+// two rows (w0: y index 0, w1: y index 1), both column classes: returns the a-column and b-column samples
+__device__ __forceinline__ void bayer4_rows(uint32_t w0, uint32_t w1, float xa, float xb, float y, uint32_t& pa, uint32_t& pb) {
+	pa = bilin((float)(w0 & 0xFF), (float)((w0 >> 8) & 0xFF), (float)(w1 & 0xFF), (float)((w1 >> 8) & 0xFF), xa, y);
+	pb = bilin((float)((w0 >> 16) & 0xFF), (float)(w0 >> 24), (float)((w1 >> 16) & 0xFF), (float)(w1 >> 24), xb, y);
 }
 
 template<int LAYOUT, int MODE, bool FROM_RAW>
@@ -273,9 +312,7 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 		g = sample<LAYOUT, MODE, FROM_RAW>(s, 0, px + 0.25f, py + 0.25f, a.qw, a.qh) / 2 + sample<LAYOUT, MODE, FROM_RAW>(s, 3, px - 0.25f, py - 0.25f, a.qw, a.qh) / 2;
 		b = sample<LAYOUT, MODE, FROM_RAW>(s, 2, px + 0.25f, py - 0.25f, a.qw, a.qh);
 	}
-	// delta-RGB in uint arithmetic (:86-91); each channel is at most (2*255+510)/4 = 255
-	const uint32_t dr = (2 * r - g - b + 510) / 4, dg = (2 * g - b - r + 510) / 4, db = (2 * b - r - g + 510) / 4;
-	const uint32_t px4 = min(dr, 255u) | (min(dg, 255u) << 8) | (min(db, 255u) << 16) | 0xFF000000u;
+	const uint32_t px4 = drgb_pack(r, g, b); // :86-91
 	reinterpret_cast<uint32_t*>(flat)[(size_t)blockIdx.z * a.fw * a.fh + (size_t)gy * a.fw + gx] = px4;
 	emit_strip(a.strips, blockIdx.z, gx, gy, px4);
 }
@@ -331,12 +368,13 @@ constexpr int RESAMPLE_FPT = 8;
 // Boxes too large for the stage (exotic geometries) take the direct path; results are identical either way.
 constexpr int STAGE_DW = 1024; // dwords per stage buffer
 
-template<int LAYOUT, int MODE>
-__global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
+// Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
+// sample directly (bayer4_eval); results are identical either way.
+template<int LAYOUT>
+__global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
-	__shared__ uint32_t stage[2][STAGE_DW + 4];
+	__shared__ uint32_t stage[2][STAGE_DW];
 	__shared__ int red[4][4];
-	// 1-D grid, XCD-aware (vp_xcd_remap): consecutive logical ids walk along x, then y, then the frame group
 	const unsigned nbx = (unsigned)(fw + 63) / 64, nby = (unsigned)(fh + 3) / 4;
 	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
 	const unsigned bz = lb / (nbx * nby), brem = lb - bz * nbx * nby;
@@ -346,15 +384,12 @@ __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restri
 	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
 	const float px = pos.x, py = pos.y;
 	const int f0 = (int)bz * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
-	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)min(gy, fh - 1) * fw + min(gx, fw - 1);
 	const size_t npx = (size_t)fw * fh;
-	if(LAYOUT != VP_LAYOUT_BGR && MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
-		const Bayer4Geom g = bayer4_geom(px, py, qw, qh);
-		const uint32_t rowb = 2u * (uint32_t)qw;
-		// bounding box of this workgroup's windows: byte columns [cmin, cmax), sensor rows [rmin, rmax]
-		const int c_lo = (int)(g.off_e0 % rowb);
-		const int re0 = (int)(g.off_e0 / rowb), re1 = (int)(g.off_e1 / rowb), ro0 = (int)(g.off_o0 / rowb), ro1 = (int)(g.off_o1 / rowb);
-		int cmin = c_lo, cmax = c_lo + 8, rmin = min(min(re0, re1), min(ro0, ro1)), rmax = max(max(re0, re1), max(ro0, ro1));
+	const uint32_t rowb = 2u * (uint32_t)qw;
+	{
+		const Bayer4Stage g = bayer4_stage(px, py, qw, qh);
+		// bounding box of this workgroup's windows: dword columns [cmin, cmax), sensor rows [rmin, rmax]
+		int cmin = g.d0, cmax = g.d0 + 2, rmin = min(min(g.re0, g.re1), min(g.ro0, g.ro1)), rmax = max(max(g.re0, g.re1), max(g.ro0, g.ro1));
 #pragma unroll
 		for(int d = 32; d > 0; d >>= 1) {
 			cmin = min(cmin, __shfl_xor(cmin, d, 64));
@@ -374,47 +409,100 @@ __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restri
 		cmax = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
 		rmin = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
 		rmax = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-		const int c0 = cmin & ~3, wdw = (cmax - c0 + 3) >> 2, hr = rmax - rmin + 1, ndw = wdw * hr;
-		// (a single frame per thread cannot hide the stage's round trip behind the previous frame's arithmetic: direct path)
-		const bool staged = f1 - f0 >= 2 && ndw <= STAGE_DW && (qw & 1) == 0 && ((reinterpret_cast<uintptr_t>(raw) | src_frame_bytes) & 3) == 0;
-		if(staged) { // workgroup-uniform
-			// which dwords of the box this thread fetches (<= 4), and where its own windows start inside the box
-			uint32_t goff[STAGE_DW / 256];
+		const int wdw = cmax - cmin, hr = rmax - rmin + 1, ndw = wdw * hr;
+		const size_t raw_span = (size_t)(f1 - f0) * src_frame_bytes, flat_span = (size_t)(f1 - f0) * npx * 4;
+		if(ndw <= STAGE_DW && raw_span < 0x7fffffffu && flat_span < 0x7fffffffu && (size_t)(f1 - f0) * strips.frame_words * 4 < 0x7fffffffu) {
+			// buffer addressing: descriptor in SGPRs (rebased to this frame group), 32-bit per-lane offset, per-frame scalar
+			// offset -- no 64-bit VALU address arithmetic inside the frame loop
+			const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)f0 * src_frame_bytes, 0, (int)raw_span, 0x00020000);
+			const __amdgpu_buffer_rsrc_t rs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)f0 * npx * 4, 0, (int)flat_span, 0x00020000);
+			const __amdgpu_buffer_rsrc_t rs_strip = __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)f0 * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
+					(int)((size_t)(f1 - f0) * strips.frame_words * 4), 0x00020000);
+			const uint32_t fb_raw = (uint32_t)src_frame_bytes, fb_flat = (uint32_t)(npx * 4), fb_strip = (uint32_t)(strips.frame_words * 4);
+			const uint32_t voff_out = 4u * (uint32_t)(min(gy, fh - 1) * fw + min(gx, fw - 1));
+			// halo-strip destinations of this pixel (emit_strip(), hoisted out of the frame loop)
+			const int xm = gx & 63, tb = gx >> 6;
+			const bool sl = valid && strips.base && xm >= 64 - strips.o && tb + 1 < strips.tiles_x, sr = valid && strips.base && xm < strips.o && tb > 0;
+			const uint32_t voff_sl = sl ? 4u * (uint32_t)strips.left(tb + 1, gy, xm - (64 - strips.o)) : 0u, voff_sr = sr ? 4u * (uint32_t)strips.right(tb, gy, xm) : 0u;
+			const int wcol = g.d0 - cmin;
+			const int ie0 = (g.re0 - rmin) * wdw + wcol, ie1 = (g.re1 - rmin) * wdw + wcol, io0 = (g.ro0 - rmin) * wdw + wcol, io1 = (g.ro1 - rmin) * wdw + wcol;
+			// which dwords of the box this thread fetches, NP pieces of 256 (lanes past the box re-fetch its first dword: harmless)
+			auto run = [&](auto np) {
+				constexpr int NP = decltype(np)::value;
+				uint32_t goff[NP], pre[NP];
 #pragma unroll
-			for(int k = 0; k < STAGE_DW / 256; k++) {
-				const int i = tid + 256 * k, r = i / wdw, c = i - r * wdw;
-				goff[k] = (uint32_t)(rmin + r) * rowb + (uint32_t)c0 + 4u * (uint32_t)c;
-			}
-			const int wcol = (c_lo - c0) >> 2;
-			const uint32_t sh = (uint32_t)(c_lo - c0) & 3u; // 0 or 2
-			const int ie0 = (re0 - rmin) * wdw + wcol, ie1 = (re1 - rmin) * wdw + wcol, io0 = (ro0 - rmin) * wdw + wcol, io1 = (ro1 - rmin) * wdw + wcol;
-			uint32_t pre[STAGE_DW / 256];
-			const uint8_t* fr = raw + (size_t)f0 * src_frame_bytes;
-#pragma unroll
-			for(int k = 0; k < STAGE_DW / 256; k++) pre[k] = (tid + 256 * k < ndw) ? *reinterpret_cast<const uint32_t*>(fr + goff[k]) : 0u;
-			int buf = 0;
-			for(int f = f0; f < f1; f++, buf ^= 1) {
-#pragma unroll
-				for(int k = 0; k < STAGE_DW / 256; k++)
-					if(tid + 256 * k < ndw) stage[buf][tid + 256 * k] = pre[k];
-				__syncthreads();
-				if(f + 1 < f1) { // next frame's box -> registers while this one is consumed
-					fr = raw + (size_t)(f + 1) * src_frame_bytes;
-#pragma unroll
-					for(int k = 0; k < STAGE_DW / 256; k++) pre[k] = (tid + 256 * k < ndw) ? *reinterpret_cast<const uint32_t*>(fr + goff[k]) : 0u;
+				for(int k = 0; k < NP; k++) {
+					const int i = tid + 256 * k < ndw ? tid + 256 * k : 0, r = i / wdw, c = i - r * wdw;
+					goff[k] = (uint32_t)(rmin + r) * rowb + 4u * (uint32_t)(cmin + c);
 				}
-				const uint32_t* st = stage[buf];
-				auto window = [&](int i) { return make_uint2(__builtin_amdgcn_alignbyte(st[i + 1], st[i], sh), __builtin_amdgcn_alignbyte(st[i + 2], st[i + 1], sh)); };
-				uint32_t p[4];
-				bayer4_combine(window(ie0), window(ie1), window(io0), window(io1), g, p);
-				const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
-				if(valid) {
-					out[(size_t)f * npx] = px4;
-					emit_strip(strips, f, gx, gy, px4);
+				// Per frame: [barrier] issue the next frame's box loads -> sample this frame from stage[B] -> park the loaded box
+				// in stage[1-B] -> store.  The vmcnt wait before the LDS write then covers only loads issued a full frame of
+				// arithmetic earlier and stores one frame older still, never the stores just issued.
+#pragma unroll
+				for(int k = 0; k < NP; k++) stage[0][tid + 256 * k] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff[k], 0, 0);
+				auto frame = [&](int f, auto bufc) {
+					constexpr int B = decltype(bufc)::value;
+					__syncthreads();
+					const bool more = f + 1 < f1;
+					if(more) {
+#pragma unroll
+						for(int k = 0; k < NP; k++) pre[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff[k], (uint32_t)(f + 1 - f0) * fb_raw, 0);
+					}
+					const uint32_t* st = stage[B];
+					auto window = [&](int i) { return __builtin_amdgcn_perm(st[i + 1], st[i], g.sel); };
+					uint32_t p[4];
+					bayer4_rows(window(ie0), window(ie1), g.xa, g.xb, g.ya, p[0], p[1]);
+					bayer4_rows(window(io0), window(io1), g.xa, g.xb, g.yb, p[2], p[3]);
+					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+					if(more) {
+#pragma unroll
+						for(int k = 0; k < NP; k++) stage[1 - B][tid + 256 * k] = pre[k];
+					}
+					const uint32_t fo = (uint32_t)(f - f0);
+					// (lanes past the right/bottom edge hold the clamped pixel's own value: the duplicate store is harmless)
+					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, fo * fb_flat, 0);
+					if(sl) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sl, fo * fb_strip, 0);
+					if(sr) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sr, fo * fb_strip, 0);
+				};
+				for(int f = f0; f < f1; f += 2) {
+					frame(f, std::integral_constant<int, 0>());
+					if(f + 1 < f1) frame(f + 1, std::integral_constant<int, 1>());
 				}
-			}
+			};
+			if(ndw <= 256) run(std::integral_constant<int, 1>());
+			else run(std::integral_constant<int, STAGE_DW / 256>());
 			return;
 		}
+	}
+	if(!valid) return;
+	const Bayer4Geom gd = bayer4_geom(px, py, qw, qh);
+	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)gy * fw + gx;
+	for(int f = f0; f < f1; f++) {
+		uint32_t p[4];
+		bayer4_eval(raw + (size_t)f * src_frame_bytes, gd, p);
+		const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+		out[(size_t)f * npx] = px4;
+		emit_strip(strips, f, gx, gy, px4);
+	}
+}
+
+template<int LAYOUT, int MODE>
+__global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
+		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
+	// 1-D grid, XCD-aware (vp_xcd_remap): consecutive logical ids walk along x, then y, then the frame group
+	const unsigned nbx = (unsigned)(fw + 63) / 64, nby = (unsigned)(fh + 3) / 4;
+	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
+	const unsigned bz = lb / (nbx * nby), brem = lb - bz * nbx * nby;
+	const int gx = (int)(brem % nbx) * 64 + threadIdx.x;
+	const int gy = (int)(brem / nbx) * 4 + threadIdx.y;
+	const bool valid = gx < fw && gy < fh;
+	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
+	const float px = pos.x, py = pos.y;
+	const int f0 = (int)bz * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
+	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)min(gy, fh - 1) * fw + min(gx, fw - 1);
+	const size_t npx = (size_t)fw * fh;
+	if(LAYOUT != VP_LAYOUT_BGR && MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
+		const Bayer4Geom g = bayer4_geom(px, py, qw, qh);
 		if(!valid) return;
 #pragma unroll 2
 		for(int f = f0; f < f1; f++) {
@@ -492,6 +580,14 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	const dim3 grid(vp_div_up(fw, 64) * vp_div_up(fh, 4) * vp_div_up(batch, RESAMPLE_FPT)), block(64, 4);
 	hipStream_t s = ctx->streams[stream];
 	const float2* m2 = reinterpret_cast<const float2*>(map);
+	// staged kernel: Bayer + BILINEAR_RTZ with dword-aligned sensor rows; a frame group's spans must fit the 32-bit buffer offsets
+	const size_t span = (size_t)RESAMPLE_FPT * std::max(std::max(frame_bytes, (size_t)fw * fh * 4), strips.base ? strips.frame_words * 4 : (size_t)0);
+	if(layout != VP_LAYOUT_BGR && sampler_mode == VP_SAMPLER_BILINEAR_RTZ && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
+			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0) {
+		if(layout == VP_LAYOUT_RGGB) k_resample_staged<VP_LAYOUT_RGGB><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		else k_resample_staged<VP_LAYOUT_GRBG><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		return vp_launch_ok("raw2quad+resampling (staged)");
+	}
 #define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch)
 	if(sampler_mode == VP_SAMPLER_NEAREST) {
 		if(layout == VP_LAYOUT_RGGB) VP_RM(VP_LAYOUT_RGGB, VP_SAMPLER_NEAREST);
