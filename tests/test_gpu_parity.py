@@ -210,6 +210,40 @@ def test_live_oracle_mid_sizes(gpu, port, cfg):
         assert_list_equal(capi, (host(d["matches"][i]), host(d["idx"][i]).view(np.uint32), host(d["counter"][i])), np.frombuffer(m.tobytes(), np.uint8), idx, cnt, mm)
 
 
+RESAMPLE_BATCH_CASES = [
+    (cfgs.T_RGGB, 9),                                                      # 8 + 1: a frame group with a single frame
+    (cfgs.T_GRBG, 3),
+    (cfgs.T_RAGGED.with_(name="t_ragged_even", qw=68, qh=46), 10),          # even rows -> staged; flat overhangs all four sensor edges
+    (cfgs.T_RAGGED, 5),                                                    # odd quad width -> unstaged kernel
+    (cfgs.T_MID.with_(name="t_mid_wide", visible_len=9000.0), 4),          # strong minification: large bounding boxes per workgroup
+    (cfgs.T_BGR, 3),
+]
+
+
+@pytest.mark.parametrize("cfg,B", RESAMPLE_BATCH_CASES, ids=[c.name for c, _ in RESAMPLE_BATCH_CASES])
+@pytest.mark.parametrize("mode", [0, 1], ids=["nearest", "bilinear_rtz"])
+def test_resample_mapped_batches(gpu, port, cfg, B, mode):
+    """Coordinate-map resampling over whole batches (the staged LDS kernel for Bayer + BILINEAR_RTZ) against the CPU oracle, per frame."""
+    capi, ctx, torch = gpu
+    model = cfg.model()
+    model_o = O.CameraModel.from_array(np.frombuffer(bytes(model), np.uint8))
+    raws = [cfg.synth(300 + 7 * i) for i in range(B)]
+    # make the sensor borders count: saturate a frame of pixels so clamp-to-edge taps are distinguishable
+    for r in raws:
+        r[:2], r[-2:], r[:, :2], r[:, -2:] = 250, 5, 3, 247
+    d_raw = dev(torch, np.stack(raws))
+    d_map = torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda")
+    ctx.resample_map(model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, d_map)
+    d_flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+    ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, d_map, mode, cfg.fw, cfg.fh, B, d_flat)
+    ctx.sync()
+    got = host(d_flat)
+    for i in range(B):
+        planes = port.raw2quad(raws[i], cfg.layout, cfg.qw, cfg.qh)
+        want = port.resample(planes, cfg.layout, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, mode, cfg.fw, cfg.fh)
+        assert np.array_equal(got[i], want), f"frame {i}"
+
+
 def test_full_size_properties(gpu, port):
     """BASELINE.json configs[1] (2048x1536): properties that do not need a full CPU reference run per frame."""
     capi, ctx, torch = gpu
