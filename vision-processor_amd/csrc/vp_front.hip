@@ -366,20 +366,35 @@ constexpr int RESAMPLE_FPT = 8;
 // wave load).  So the workgroup finds the bounding box of its windows once (frame independent), then per frame stages that box
 // in LDS with ONE coalesced dword load per thread (double buffered, one barrier per frame) and reads the windows from LDS.
 // Boxes too large for the stage (exotic geometries) take the direct path; results are identical either way.
-constexpr int STAGE_DW = 1024; // dwords per stage buffer
+constexpr int STAGE_DW = 512; // dwords per frame box in the stage
+
+// packed-u16 min / max (v_pk_min_u16 / v_pk_max_u16) and their wave reductions in DPP (row_shr 1,2,4,8, row_bcast 15 and 31; the
+// result is read from lane 63)
+typedef unsigned short vp_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk16_min(uint32_t a, uint32_t b) {
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(vp_u16x2, a), __builtin_bit_cast(vp_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk16_max(uint32_t a, uint32_t b) {
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vp_u16x2, a), __builtin_bit_cast(vp_u16x2, b)));
+}
+template<bool MAX>
+__device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
+#define VP_DPP_STEP(ctrl, rowmask) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rowmask, 0xf, false); v = MAX ? pk16_max(v, t) : pk16_min(v, t); }
+	VP_DPP_STEP(0x111, 0xf) VP_DPP_STEP(0x112, 0xf) VP_DPP_STEP(0x114, 0xf) VP_DPP_STEP(0x118, 0xf) VP_DPP_STEP(0x142, 0xa) VP_DPP_STEP(0x143, 0xc)
+#undef VP_DPP_STEP
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 // Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
 // sample directly (bayer4_eval); results are identical either way.
 template<int LAYOUT>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
-	__shared__ uint32_t stage[2][STAGE_DW];
-	__shared__ int red[4][4];
-	const unsigned nbx = (unsigned)(fw + 63) / 64, nby = (unsigned)(fh + 3) / 4;
-	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
-	const unsigned bz = lb / (nbx * nby), brem = lb - bz * nbx * nby;
-	const int gx = (int)(brem % nbx) * 64 + threadIdx.x;
-	const int gy = (int)(brem / nbx) * 4 + threadIdx.y;
+	__shared__ uint32_t stage[RESAMPLE_FPT][STAGE_DW];
+	__shared__ uint32_t red[4][2];
+	const unsigned bz = blockIdx.z;
+	const int gx = (int)blockIdx.x * 64 + threadIdx.x;
+	const int gy = (int)blockIdx.y * 4 + threadIdx.y;
 	const bool valid = gx < fw && gy < fh;
 	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
 	const float px = pos.x, py = pos.y;
@@ -389,26 +404,18 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 	{
 		const Bayer4Stage g = bayer4_stage(px, py, qw, qh);
 		// bounding box of this workgroup's windows: dword columns [cmin, cmax), sensor rows [rmin, rmax]
-		int cmin = g.d0, cmax = g.d0 + 2, rmin = min(min(g.re0, g.re1), min(g.ro0, g.ro1)), rmax = max(max(g.re0, g.re1), max(g.ro0, g.ro1));
-#pragma unroll
-		for(int d = 32; d > 0; d >>= 1) {
-			cmin = min(cmin, __shfl_xor(cmin, d, 64));
-			cmax = max(cmax, __shfl_xor(cmax, d, 64));
-			rmin = min(rmin, __shfl_xor(rmin, d, 64));
-			rmax = max(rmax, __shfl_xor(rmax, d, 64));
-		}
+		// (both fit 16 bits: checked by the host; one packed 16-bit min and max reduction over the workgroup, DPP within a wave)
+		const uint32_t lo_w = wave_reduce_pk16<false>((uint32_t)g.d0 | ((uint32_t)min(g.re0, g.ro0) << 16));
+		const uint32_t hi_w = wave_reduce_pk16<true>((uint32_t)(g.d0 + 2) | ((uint32_t)max(g.re1, g.ro1) << 16));
 		const int tid = threadIdx.y * 64 + threadIdx.x;
 		if(threadIdx.x == 0) {
-			red[threadIdx.y][0] = cmin;
-			red[threadIdx.y][1] = cmax;
-			red[threadIdx.y][2] = rmin;
-			red[threadIdx.y][3] = rmax;
+			red[threadIdx.y][0] = lo_w;
+			red[threadIdx.y][1] = hi_w;
 		}
 		__syncthreads();
-		cmin = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-		cmax = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
-		rmin = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
-		rmax = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+		const uint32_t lo = pk16_min(pk16_min(red[0][0], red[1][0]), pk16_min(red[2][0], red[3][0]));
+		const uint32_t hi = pk16_max(pk16_max(red[0][1], red[1][1]), pk16_max(red[2][1], red[3][1]));
+		const int cmin = (int)(lo & 0xFFFF), rmin = (int)(lo >> 16), cmax = (int)(hi & 0xFFFF), rmax = (int)(hi >> 16);
 		const int wdw = cmax - cmin, hr = rmax - rmin + 1, ndw = wdw * hr;
 		const size_t raw_span = (size_t)(f1 - f0) * src_frame_bytes, flat_span = (size_t)(f1 - f0) * npx * 4;
 		if(ndw <= STAGE_DW && raw_span < 0x7fffffffu && flat_span < 0x7fffffffu && (size_t)(f1 - f0) * strips.frame_words * 4 < 0x7fffffffu) {
@@ -423,50 +430,51 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			// halo-strip destinations of this pixel (emit_strip(), hoisted out of the frame loop)
 			const int xm = gx & 63, tb = gx >> 6;
 			const bool sl = valid && strips.base && xm >= 64 - strips.o && tb + 1 < strips.tiles_x, sr = valid && strips.base && xm < strips.o && tb > 0;
-			const uint32_t voff_sl = sl ? 4u * (uint32_t)strips.left(tb + 1, gy, xm - (64 - strips.o)) : 0u, voff_sr = sr ? 4u * (uint32_t)strips.right(tb, gy, xm) : 0u;
+			const uint32_t so = (uint32_t)strips.o, sh = (uint32_t)strips.h; // VpStrips::left/right in 32-bit arithmetic (frame_words * 4 < 2 GiB)
+			const uint32_t voff_sl = sl ? 4u * (((uint32_t)(tb + 1) * sh + (uint32_t)gy) * so + (uint32_t)(xm - 64) + so) : 0u;
+			const uint32_t voff_sr = sr ? 4u * (((uint32_t)(strips.tiles_x + tb) * sh + (uint32_t)gy) * so + (uint32_t)xm) : 0u;
 			const int wcol = g.d0 - cmin;
 			const int ie0 = (g.re0 - rmin) * wdw + wcol, ie1 = (g.re1 - rmin) * wdw + wcol, io0 = (g.ro0 - rmin) * wdw + wcol, io1 = (g.ro1 - rmin) * wdw + wcol;
 			// which dwords of the box this thread fetches, NP pieces of 256 (lanes past the box re-fetch its first dword: harmless)
+			const float inv_wdw = __builtin_amdgcn_rcpf((float)wdw);
+			const int nf = f1 - f0;
+			// On gfx9-family hardware loads and stores share one vmcnt and complete out of order with respect to each other, so a
+			// wave that waits for a load while one of its stores is in flight drains both (measured: +185 us per 128 frames when
+			// the box of frame f+1 was fetched while frame f was being stored).  Hence: fetch the boxes of ALL frames of the group
+			// first (one wait, no store pending), park them in LDS, one barrier, then sample and store frame after frame with no
+			// further memory waits.  Other workgroups on the CU cover the fetch phase.
 			auto run = [&](auto np) {
-				constexpr int NP = decltype(np)::value;
-				uint32_t goff[NP], pre[NP];
+				constexpr int NP = decltype(np)::value; // pieces of 256 dwords per frame box
+				uint32_t goff[NP], pre[RESAMPLE_FPT][NP];
 #pragma unroll
 				for(int k = 0; k < NP; k++) {
-					const int i = tid + 256 * k < ndw ? tid + 256 * k : 0, r = i / wdw, c = i - r * wdw;
+					// r = i / wdw without the integer-division sequence: (i + 0.5) / wdw stays >= 0.5 / wdw away from every integer while
+					// the product's error is below 1e-6 * STAGE_DW / wdw.  Lanes past the box re-fetch its first dword (harmless).
+					const int i = tid + 256 * k < ndw ? tid + 256 * k : 0, r = (int)(((float)i + 0.5f) * inv_wdw), c = i - r * wdw;
 					goff[k] = (uint32_t)(rmin + r) * rowb + 4u * (uint32_t)(cmin + c);
 				}
-				// Per frame: [barrier] issue the next frame's box loads -> sample this frame from stage[B] -> park the loaded box
-				// in stage[1-B] -> store.  The vmcnt wait before the LDS write then covers only loads issued a full frame of
-				// arithmetic earlier and stores one frame older still, never the stores just issued.
 #pragma unroll
-				for(int k = 0; k < NP; k++) stage[0][tid + 256 * k] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff[k], 0, 0);
-				auto frame = [&](int f, auto bufc) {
-					constexpr int B = decltype(bufc)::value;
-					__syncthreads();
-					const bool more = f + 1 < f1;
-					if(more) {
+				for(int j = 0; j < RESAMPLE_FPT; j++)
 #pragma unroll
-						for(int k = 0; k < NP; k++) pre[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff[k], (uint32_t)(f + 1 - f0) * fb_raw, 0);
-					}
-					const uint32_t* st = stage[B];
+					for(int k = 0; k < NP; k++) pre[j][k] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff[k], (uint32_t)min(j, nf - 1) * fb_raw, 0);
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++)
+#pragma unroll
+					for(int k = 0; k < NP; k++) stage[j][tid + 256 * k] = pre[j][k];
+				__syncthreads();
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) {
+					if(j >= nf) break;
+					const uint32_t* st = stage[j];
 					auto window = [&](int i) { return __builtin_amdgcn_perm(st[i + 1], st[i], g.sel); };
 					uint32_t p[4];
 					bayer4_rows(window(ie0), window(ie1), g.xa, g.xb, g.ya, p[0], p[1]);
 					bayer4_rows(window(io0), window(io1), g.xa, g.xb, g.yb, p[2], p[3]);
 					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
-					if(more) {
-#pragma unroll
-						for(int k = 0; k < NP; k++) stage[1 - B][tid + 256 * k] = pre[k];
-					}
-					const uint32_t fo = (uint32_t)(f - f0);
 					// (lanes past the right/bottom edge hold the clamped pixel's own value: the duplicate store is harmless)
-					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, fo * fb_flat, 0);
-					if(sl) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sl, fo * fb_strip, 0);
-					if(sr) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sr, fo * fb_strip, 0);
-				};
-				for(int f = f0; f < f1; f += 2) {
-					frame(f, std::integral_constant<int, 0>());
-					if(f + 1 < f1) frame(f + 1, std::integral_constant<int, 1>());
+					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
+					if(sl) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sl, (uint32_t)j * fb_strip, 0);
+					if(sr) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sr, (uint32_t)j * fb_strip, 0);
 				}
 			};
 			if(ndw <= 256) run(std::integral_constant<int, 1>());
@@ -583,7 +591,8 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	// staged kernel: Bayer + BILINEAR_RTZ with dword-aligned sensor rows; a frame group's spans must fit the 32-bit buffer offsets
 	const size_t span = (size_t)RESAMPLE_FPT * std::max(std::max(frame_bytes, (size_t)fw * fh * 4), strips.base ? strips.frame_words * 4 : (size_t)0);
 	if(layout != VP_LAYOUT_BGR && sampler_mode == VP_SAMPLER_BILINEAR_RTZ && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
-			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0) {
+			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
+		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
 		if(layout == VP_LAYOUT_RGGB) k_resample_staged<VP_LAYOUT_RGGB><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
 		else k_resample_staged<VP_LAYOUT_GRBG><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
 		return vp_launch_ok("raw2quad+resampling (staged)");
