@@ -246,20 +246,37 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	extern __shared__ __attribute__((aligned(16))) char smem_tail[];
 	const int r = RT > 0 ? RT : r_arg;
 	const int halo = r + 1;
-	const int RW = FT_W + 2 * halo, RH = FT_H + 2 * halo;
-	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - halo + rx)]
+	// horizontal halo rounded up to whole 16-byte groups when the radius is a compile-time constant: interior tiles are then
+	// fetched with aligned dwordx4 loads and no clamping (the two paths fill the same LDS layout)
+	const int HA = RT > 0 ? ((RT + 1 + 3) & ~3) : halo, XO = HA - halo;
+	const int RW = FT_W + 2 * HA, RH = FT_H + 2 * halo;
+	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - HA + rx)]
 	const int z = blockIdx.z;
 	const size_t n = (size_t)w * h;
 	const int32_t* sat = sat_all + z * n;
 	const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
 	const int tid = threadIdx.x;
-	if(NE > 0) {
+	const bool interior = RT > 0 && x0 - HA >= 0 && x0 + FT_W + HA <= w && y0 - halo >= 0 && y0 + FT_H + halo <= h && (w & 3) == 0 &&
+			(reinterpret_cast<uintptr_t>(sat_all) & 15) == 0;
+	if(interior) { // workgroup-uniform
+		constexpr int RW4 = RT > 0 ? (FT_W + 2 * ((RT + 1 + 3) & ~3)) / 4 : 1, RHc = RT > 0 ? FT_H + 2 * (RT + 1) : 1, NV = (RW4 * RHc + 255) / 256;
+		const int32_t* tb = sat + (size_t)(y0 - halo) * w + (x0 - HA); // uniform base; 32-bit lane offsets below
+		int4 v4[NV];
+#pragma unroll
+		for(int k = 0; k < NV; k++) {
+			const int i = min(tid + 256 * k, RW4 * RHc - 1), row = i / RW4, c4 = i - row * RW4;
+			v4[k] = *reinterpret_cast<const int4*>(tb + (uint32_t)(row * w + 4 * c4));
+		}
+#pragma unroll
+		for(int k = 0; k < NV; k++)
+			if(tid + 256 * k < RW4 * RHc) reinterpret_cast<int4*>(region)[tid + 256 * k] = v4[k];
+	} else if(NE > 0) {
 		uint32_t v[NE > 0 ? NE : 1];
 		const int total = RW * RH, dq = 256 / RW, dr = 256 - dq * RW;
 		int ry = tid / RW, rx = tid - ry * RW;
 #pragma unroll
 		for(int k = 0; k < NE; k++) {
-			v[k] = (k * 256 + tid < total) ? (uint32_t)sat[(size_t)vp_clampi(y0 - halo + ry, 0, h - 1) * w + vp_clampi(x0 - halo + rx, 0, w - 1)] : 0u;
+			v[k] = (k * 256 + tid < total) ? (uint32_t)sat[(size_t)vp_clampi(y0 - halo + ry, 0, h - 1) * w + vp_clampi(x0 - HA + rx, 0, w - 1)] : 0u;
 			ry += dq;
 			rx += dr;
 			if(rx >= RW) {
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	} else {
 		for(int ry = tid >> 6; ry < RH; ry += 4) {
 			const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
-			for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - halo + rx, 0, w - 1)];
+			for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - HA + rx, 0, w - 1)];
 		}
 	}
 	__syncthreads();
@@ -286,11 +303,11 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	int32_t* bx = reinterpret_cast<int32_t*>(region + RW * RH);
 	for(int e = tid; e < BXW * BXH; e += 256) {
 		const int by = e / BXW, bxx = e - by * BXW;
-		const uint32_t* c = region + by * RW + bxx;
+		const uint32_t* c = region + by * RW + bxx + XO;
 		bx[e] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
 	}
 	__syncthreads();
-	const float div = (float)(r * r);
+	const float div = (float)(r * r), rcp = 1.0f / div;
 	constexpr int BW = FT_W + 2, BH = FT_H + 2;
 	float* bc = reinterpret_cast<float*>(region); // the blobCenter ring tile aliases the (now dead) SAT region
 	for(int e = tid; e < BW * BH; e += 256) {
@@ -303,7 +320,14 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 		const float pn = (float)(-c[-r * BXW + 1]);
 		const float np = (float)(-c[BXW - r]);
 		const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
-		bc[e] = (b < a ? b : a) / div;
+		const float m = b < a ? b : a;
+		if(RT >= 3 && RT <= 10) {
+			// m / (r*r), correctly rounded, without the division sequence: q0 = m*rcp, e = fma(-d, q0, m), q = fma(e, rcp, q0).
+			// Exhaustively verified equal to m / d for every float m = (float)n, |n| <= 2^27, d = 9 .. 100 (tools/divcheck.hip);
+			// the box sums here are bounded by 100 * 3 * 255^2 < 2^25.
+			const float q0 = m * rcp;
+			bc[e] = __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
+		} else bc[e] = m / div;
 	}
 	__syncthreads();
 	for(int e = tid; e < FT_W * FT_H; e += 256) {
@@ -338,7 +362,8 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 				w, h, min_score, radius, max_matches, 0);
 	} else {
 		const int halo = circle_radius + 1;
-		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
+		const int ha = (circle_radius >= 3 && circle_radius <= 10) ? ((halo + 3) & ~3) : halo; // k_circle_detect: aligned horizontal halo of the specialised radii
+		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * ha) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
 		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + 255) / 256;
 		const dim3 grid(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch);
@@ -347,7 +372,7 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
 			k_circle_detect<N, R><<<grid, 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
 		} while(0)
-#define VP_CD_R(R) case R: VP_CD(((FT_W + 2 * (R + 1)) * (FT_H + 2 * (R + 1)) + 255) / 256, R); break
+#define VP_CD_R(R) case R: VP_CD(((FT_W + 2 * ((R + 1 + 3) & ~3)) * (FT_H + 2 * (R + 1)) + 255) / 256, R); break
 		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale)): compile-time specialisations
 			VP_CD_R(3); VP_CD_R(4); VP_CD_R(5); VP_CD_R(6); VP_CD_R(7); VP_CD_R(8); VP_CD_R(9); VP_CD_R(10);
 		default:
