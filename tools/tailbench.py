@@ -1,0 +1,35 @@
+"""A/B timing of the fused tail (circle+detect, emit, rank) on real SAT tables (tools only).  usage: tailbench.py BATCH [VP_CD_DEBUG values ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from _vp_pkg import load
+vp = load(); capi = vp.load_capi()
+cfg = vp.configs.ALL[os.environ.get("VP_CFG", "cfg2_2048x1536_rggb")]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+variants = [int(v) for v in sys.argv[2:]] or [0]
+ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+raw4 = torch.from_numpy(np.stack([cfg.synth(i) for i in range(4)])).cuda()
+raw = raw4.repeat((B + 3) // 4, *([1] * (raw4.dim() - 1)))[:B].contiguous()
+mm = cfg.max_matches
+d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+         matches=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"),
+         counter=torch.zeros((B, 3), dtype=torch.int32, device="cuda"))
+p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+ctx.frame(p, raw, B, **d); ctx.sync()
+res = {v: [] for v in variants}
+def run(N=10):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(N):
+        ctx.blobcenter_list(d["flat"], d["sat"], cfg.fw, cfg.fh, B, cfg.circle_radius, cfg.circ_threshold, cfg.min_score, cfg.list_radius, mm, capi.ORDER_RASTER,
+                            d["matches"], d["idx"], d["counter"])
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / N * 1000
+for rnd in range(6):
+    for v in variants:
+        os.environ['VP_CD_DEBUG'] = str(v)
+        t = run(3) if rnd == 0 else run()
+        if rnd: res[v].append(t)
+for v, ts in res.items():
+    med = float(np.median(ts))
+    print(f"tail {cfg.name} B={B} debug={v}: median {med:.1f} us/launch (min {min(ts):.1f}), {med/B:.2f} us/frame")

@@ -230,9 +230,9 @@ __global__ __launch_bounds__(256) void k_copy_back(const uint8_t* __restrict__ r
 }
 
 // circle + detect fused: the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge addressing (satBlobCenter.cl:20, H7),
-// blobCenter is computed for the 64x32 tile plus a 1-pixel ring into LDS, then thresholded / peak-tested (blobList.cl:37-55).
+// blobCenter is computed for the 64x64 tile plus a 1-pixel ring into LDS, then thresholded / peak-tested (blobList.cl:37-55).
 // Out-of-image ring positions take the value of the clamped position, exactly what the clamped reads of the reference return.
-constexpr int FT_W = 64, FT_H = 32;
+constexpr int FT_W = 64, FT_H = 64, FT_NT = 512; // tile and threads per workgroup (64x64: region / tile = 1.48, 64x32 was 1.72)
 
 // NE: region elements per thread held in registers so that ALL global loads are in flight before the first LDS store
 // (a plain load->store loop with run-time bounds is not unrolled and pays one memory round trip per iteration); NE = 0
@@ -241,7 +241,7 @@ constexpr int FT_W = 64, FT_H = 32;
 // (measured: SQ_ACTIVE_INST_VALU == kernel time); with RT fixed every tap offset, the region pitch and the divisions by it
 // fold into immediates.
 template<int NE, int RT>
-__global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
+__global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
 		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r_arg, float thr) {
 	extern __shared__ __attribute__((aligned(16))) char smem_tail[];
 	const int r = RT > 0 ? RT : r_arg;
@@ -259,24 +259,24 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	const bool interior = RT > 0 && x0 - HA >= 0 && x0 + FT_W + HA <= w && y0 - halo >= 0 && y0 + FT_H + halo <= h && (w & 3) == 0 &&
 			(reinterpret_cast<uintptr_t>(sat_all) & 15) == 0;
 	if(interior) { // workgroup-uniform
-		constexpr int RW4 = RT > 0 ? (FT_W + 2 * ((RT + 1 + 3) & ~3)) / 4 : 1, RHc = RT > 0 ? FT_H + 2 * (RT + 1) : 1, NV = (RW4 * RHc + 255) / 256;
+		constexpr int RW4 = RT > 0 ? (FT_W + 2 * ((RT + 1 + 3) & ~3)) / 4 : 1, RHc = RT > 0 ? FT_H + 2 * (RT + 1) : 1, NV = (RW4 * RHc + FT_NT - 1) / FT_NT;
 		const int32_t* tb = sat + (size_t)(y0 - halo) * w + (x0 - HA); // uniform base; 32-bit lane offsets below
 		int4 v4[NV];
 #pragma unroll
 		for(int k = 0; k < NV; k++) {
-			const int i = min(tid + 256 * k, RW4 * RHc - 1), row = i / RW4, c4 = i - row * RW4;
+			const int i = min(tid + FT_NT * k, RW4 * RHc - 1), row = i / RW4, c4 = i - row * RW4;
 			v4[k] = *reinterpret_cast<const int4*>(tb + (uint32_t)(row * w + 4 * c4));
 		}
 #pragma unroll
 		for(int k = 0; k < NV; k++)
-			if(tid + 256 * k < RW4 * RHc) reinterpret_cast<int4*>(region)[tid + 256 * k] = v4[k];
+			if(tid + FT_NT * k < RW4 * RHc) reinterpret_cast<int4*>(region)[tid + FT_NT * k] = v4[k];
 	} else if(NE > 0) {
 		uint32_t v[NE > 0 ? NE : 1];
-		const int total = RW * RH, dq = 256 / RW, dr = 256 - dq * RW;
+		const int total = RW * RH, dq = FT_NT / RW, dr = FT_NT - dq * RW;
 		int ry = tid / RW, rx = tid - ry * RW;
 #pragma unroll
 		for(int k = 0; k < NE; k++) {
-			v[k] = (k * 256 + tid < total) ? (uint32_t)sat[(size_t)vp_clampi(y0 - halo + ry, 0, h - 1) * w + vp_clampi(x0 - HA + rx, 0, w - 1)] : 0u;
+			v[k] = (k * FT_NT + tid < total) ? (uint32_t)sat[(size_t)vp_clampi(y0 - halo + ry, 0, h - 1) * w + vp_clampi(x0 - HA + rx, 0, w - 1)] : 0u;
 			ry += dq;
 			rx += dr;
 			if(rx >= RW) {
@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 		}
 #pragma unroll
 		for(int k = 0; k < NE; k++)
-			if(k * 256 + tid < total) region[k * 256 + tid] = v[k];
+			if(k * FT_NT + tid < total) region[k * FT_NT + tid] = v[k];
 	} else {
-		for(int ry = tid >> 6; ry < RH; ry += 4) {
+		for(int ry = tid >> 6; ry < RH; ry += FT_NT / 64) {
 			const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
 			for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - HA + rx, 0, w - 1)];
 		}
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	// [x0-1-r, x0+FT_W+1], v likewise (its origin coincides with the region's); wrapping int32 arithmetic, exact.
 	const int BXW = FT_W + r + 3, BXH = FT_H + r + 3;
 	int32_t* bx = reinterpret_cast<int32_t*>(region + RW * RH);
-	for(int e = tid; e < BXW * BXH; e += 256) {
+	for(int e = tid; e < BXW * BXH; e += FT_NT) {
 		const int by = e / BXW, bxx = e - by * BXW;
 		const uint32_t* c = region + by * RW + bxx + XO;
 		bx[e] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 	const float div = (float)(r * r), rcp = 1.0f / div;
 	constexpr int BW = FT_W + 2, BH = FT_H + 2;
 	float* bc = reinterpret_cast<float*>(region); // the blobCenter ring tile aliases the (now dead) SAT region
-	for(int e = tid; e < BW * BH; e += 256) {
+	for(int e = tid; e < BW * BH; e += FT_NT) {
 		const int by = e / BW, bxx = e - by * BW;
 		// clamped centre, in Bx coordinates (origin x0-1-r, y0-1-r)
 		const int cx = vp_clampi(x0 - 1 + bxx, 0, w - 1) - (x0 - 1 - r), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - 1 - r);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_circle_detect(const int32_t* __restrict
 		} else bc[e] = m / div;
 	}
 	__syncthreads();
-	for(int e = tid; e < FT_W * FT_H; e += 256) {
+	for(int e = tid; e < FT_W * FT_H; e += FT_NT) {
 		const int ty = e / FT_W, tx = e - ty * FT_W;
 		const int x = x0 + tx, y = y0 + ty;
 		if(x >= w || y >= h) continue;
@@ -365,14 +365,14 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 		const int ha = (circle_radius >= 3 && circle_radius <= 10) ? ((halo + 3) & ~3) : halo; // k_circle_detect: aligned horizontal halo of the specialised radii
 		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * ha) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
-		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + 255) / 256;
+		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + FT_NT - 1) / FT_NT;
 		const dim3 grid(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch);
 #define VP_CD(N, R) \
 		do { \
 			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-			k_circle_detect<N, R><<<grid, 256, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
+			k_circle_detect<N, R><<<grid, FT_NT, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
 		} while(0)
-#define VP_CD_R(R) case R: VP_CD(((FT_W + 2 * ((R + 1 + 3) & ~3)) * (FT_H + 2 * (R + 1)) + 255) / 256, R); break
+#define VP_CD_R(R) case R: VP_CD(((FT_W + 2 * ((R + 1 + 3) & ~3)) * (FT_H + 2 * (R + 1)) + FT_NT - 1) / FT_NT, R); break
 		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale)): compile-time specialisations
 			VP_CD_R(3); VP_CD_R(4); VP_CD_R(5); VP_CD_R(6); VP_CD_R(7); VP_CD_R(8); VP_CD_R(9); VP_CD_R(10);
 		default:
