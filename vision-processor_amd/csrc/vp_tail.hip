@@ -251,10 +251,15 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 	const int HA = RT > 0 ? ((RT + 1 + 3) & ~3) : halo, XO = HA - halo;
 	const int RW = FT_W + 2 * HA, RH = FT_H + 2 * halo;
 	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - HA + rx)]
-	const int z = blockIdx.z;
+	// 1-D grid, XCD-aware: each XCD walks a contiguous run of tiles (row-major inside a frame), so the halo lines neighbouring
+	// tiles share are L2 hits instead of one HBM fetch per XCD
+	const unsigned tiles_x = (unsigned)(w + FT_W - 1) / FT_W, tiles_y = (unsigned)(h + FT_H - 1) / FT_H;
+	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
+	const int z = (int)(lb / (tiles_x * tiles_y));
+	const unsigned trem = lb - (unsigned)z * tiles_x * tiles_y;
 	const size_t n = (size_t)w * h;
 	const int32_t* sat = sat_all + z * n;
-	const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+	const int x0 = (int)(trem % tiles_x) * FT_W, y0 = (int)(trem / tiles_x) * FT_H;
 	const int tid = threadIdx.x;
 	const bool interior = RT > 0 && x0 - HA >= 0 && x0 + FT_W + HA <= w && y0 - halo >= 0 && y0 + FT_H + halo <= h && (w & 3) == 0 &&
 			(reinterpret_cast<uintptr_t>(sat_all) & 15) == 0;
@@ -366,7 +371,8 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * ha) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
 		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + FT_NT - 1) / FT_NT;
-		const dim3 grid(vp_div_up(w, FT_W), vp_div_up(h, FT_H), batch);
+		VP_REQUIRE((long long)vp_div_up(w, FT_W) * vp_div_up(h, FT_H) * batch < (1ll << 31), "vp_blobcenter_list: too many tiles");
+		const dim3 grid((unsigned)(vp_div_up(w, FT_W) * vp_div_up(h, FT_H) * batch));
 #define VP_CD(N, R) \
 		do { \
 			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
