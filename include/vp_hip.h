@@ -179,6 +179,31 @@ int vp_blobscore(VpContext* ctx, int stream, const uint8_t* flat, const float* b
 /* circularize (blobCenter.cl:29-63; never compiled by the reference): non-SAT quadrant ringness, for cross-checks. */
 int vp_circularize(VpContext* ctx, int stream, const float* graddot, int w, int h, int batch, int min_radius, int max_radius, float* out);
 
+/* ---- debug / stream colour kernels ------------------------------------------------------------------------
+ * NV12 frame layout (what RTPStreamer::sendFrame receives, rtpstreamer.cpp:177-181): w*h luma bytes followed by ceil(h/2) rows of
+ * w interleaved U,V bytes = vp_nv12_bytes(w, h) per frame; w must be even.  The reference lets all four pixels of a 2x2 block
+ * write the block's UV pair (quad2nv12.cl:54-57, rgba2nv12.cl:28-30: a data race); here the block's last pixel in raster order
+ * defines it, which is what a sequential execution of the reference kernel yields. */
+size_t vp_nv12_bytes(int w, int h);
+
+/* quad2rgba (quad2rgba.cl:24-53; Resources::quad2rgba, Resources.cpp:145-149): demosaiced RGBA8 at quad resolution, no dRGB.
+ * planes: batch x 4 x qh x qw; rgba: batch x qh x qw x 4.  vp_quad2rgba4: four separately acquired plane images, one frame.
+ * vp_raw2rgba: the same from the raw sensor buffer with raw2quad fused (planes never materialised). */
+int vp_quad2rgba(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* rgba);
+int vp_quad2rgba4(VpContext* ctx, int stream, const uint8_t* plane0, const uint8_t* plane1, const uint8_t* plane2, const uint8_t* plane3, int layout, int qw, int qh,
+		int sampler_mode, uint8_t* rgba);
+int vp_raw2rgba(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* rgba);
+
+/* quad2nv12 (quad2nv12.cl:24-58; Resources::streamQuad, Resources.cpp:166-170): the same colour, BT.601 limited-range NV12. */
+int vp_quad2nv12(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* nv12);
+int vp_quad2nv124(VpContext* ctx, int stream, const uint8_t* plane0, const uint8_t* plane1, const uint8_t* plane2, const uint8_t* plane3, int layout, int qw, int qh,
+		int sampler_mode, uint8_t* nv12);
+int vp_raw2nv12(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* nv12);
+
+/* rgb2nv12 (rgba2nv12.cl:22-31) and f2nv12 (f2nv12.cl:22-26): Resources::streamImage for RGBA8 / F32 images (Resources.cpp:172-186). */
+int vp_rgba2nv12(VpContext* ctx, int stream, const uint8_t* rgba, int w, int h, int batch, uint8_t* nv12);
+int vp_f2nv12(VpContext* ctx, int stream, const float* img, int w, int h, int batch, uint8_t* nv12);
+
 /* ---- whole frame: Resources::raw2quad + Resources::rgba2blobCenter + the blobList launch of main.cpp:283-289 ---------- */
 typedef struct {
 	int32_t layout, qw, qh;            /* RawImage format/width/height (opencl.h:168-188; Bayer: 2x2-cell counts) */

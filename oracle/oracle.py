@@ -214,6 +214,39 @@ class Port(_Base):
             "matches": np.zeros(max(max_matches, 1), MATCH_DTYPE), "idx": np.zeros(max(max_matches, 1), np.uint32), "counter": np.zeros(3, np.int32),
         }
 
+    # ---- debug / stream colour kernels
+    @staticmethod
+    def nv12_bytes(w, h):
+        return w * h + w * ((h + 1) // 2)
+
+    def quad2rgba(self, planes, layout, sampler_mode):
+        planes = _c(planes, np.uint8)
+        qh, qw = planes.shape[1:]
+        out = np.zeros((qh, qw, 4), np.uint8)
+        self.lib.vpo_quad2rgba(_u8(planes[0]), _u8(planes[1]), _u8(planes[2]), _u8(planes[3]), qw, qh, layout, int(sampler_mode), _u8(out))
+        return out
+
+    def quad2nv12(self, planes, layout, sampler_mode):
+        planes = _c(planes, np.uint8)
+        qh, qw = planes.shape[1:]
+        out = np.zeros(self.nv12_bytes(qw, qh), np.uint8)
+        self.lib.vpo_quad2nv12(_u8(planes[0]), _u8(planes[1]), _u8(planes[2]), _u8(planes[3]), qw, qh, layout, int(sampler_mode), _u8(out))
+        return out
+
+    def rgba2nv12(self, rgba):
+        rgba = _c(rgba, np.uint8)
+        h, w = rgba.shape[:2]
+        out = np.zeros(self.nv12_bytes(w, h), np.uint8)
+        self.lib.vpo_rgba2nv12(_u8(rgba), w, h, _u8(out))
+        return out
+
+    def f2nv12(self, img):
+        img = _c(img, np.float32)
+        h, w = img.shape
+        out = np.zeros(self.nv12_bytes(w, h), np.uint8)
+        self.lib.vpo_f2nv12(_f32(img), w, h, _u8(out))
+        return out
+
 
 class Ref(_Base):
     """The reference's own kernels (compiled from /root/reference/kernel/*.cl) behind the ref_shim.c NDRange loops."""
@@ -297,6 +330,41 @@ class Ref(_Base):
         h, w = g.shape
         out = np.zeros_like(g)
         self.lib.ref_circularize(_f32(g), w, h, int(min_r), int(max_r), _f32(out))
+        return out
+
+    # ---- debug / stream colour kernels
+    @staticmethod
+    def nv12_bytes(w, h):
+        return w * h + w * ((h + 1) // 2)
+
+    def quad2rgba(self, planes, layout, sampler_mode):
+        planes = _c(planes, np.uint8)
+        qh, qw = planes.shape[1:]
+        out = np.zeros((qh, qw, 4), np.uint8)
+        self.lib.ref_set_sampler_mode(int(sampler_mode))
+        self.lib.ref_quad2rgba(_u8(planes[0]), _u8(planes[1]), _u8(planes[2]), _u8(planes[3]), qw, qh, layout, _u8(out))
+        return out
+
+    def quad2nv12(self, planes, layout, sampler_mode):
+        planes = _c(planes, np.uint8)
+        qh, qw = planes.shape[1:]
+        out = np.zeros(self.nv12_bytes(qw, qh), np.uint8)
+        self.lib.ref_set_sampler_mode(int(sampler_mode))
+        self.lib.ref_quad2nv12(_u8(planes[0]), _u8(planes[1]), _u8(planes[2]), _u8(planes[3]), qw, qh, layout, _u8(out))
+        return out
+
+    def rgba2nv12(self, rgba):
+        rgba = _c(rgba, np.uint8)
+        h, w = rgba.shape[:2]
+        out = np.zeros(self.nv12_bytes(w, h), np.uint8)
+        self.lib.ref_rgba2nv12(_u8(rgba), w, h, _u8(out))
+        return out
+
+    def f2nv12(self, img):
+        img = _c(img, np.float32)
+        h, w = img.shape
+        out = np.zeros(self.nv12_bytes(w, h), np.uint8)
+        self.lib.ref_f2nv12(_f32(img), w, h, _u8(out))
         return out
 
 

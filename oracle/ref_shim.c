@@ -167,6 +167,13 @@ float ocl_min(float x, float y) __asm__("_Z3minff");
 float ocl_min(float x, float y) { return y < x ? y : x; }
 int ocl_atomic_inc(volatile int* p) __asm__("_Z10atomic_incPU8CLglobalVi");
 int ocl_atomic_inc(volatile int* p) { int o = *p; *p = o + 1; return o; }
+/* convert_uchar_sat (OpenCL C 6.4.3): saturating; the float overload rounds toward zero, NaN -> 0 */
+unsigned char ocl_convert_uchar_sat_u(unsigned int v) __asm__("_Z17convert_uchar_satj");
+unsigned char ocl_convert_uchar_sat_u(unsigned int v) { return v > 255u ? 255 : (unsigned char)v; }
+unsigned char ocl_convert_uchar_sat_i(int v) __asm__("_Z17convert_uchar_sati");
+unsigned char ocl_convert_uchar_sat_i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : (unsigned char)v); }
+unsigned char ocl_convert_uchar_sat_f(float v) __asm__("_Z17convert_uchar_satf");
+unsigned char ocl_convert_uchar_sat_f(float v) { return !(v > 0.0f) ? 0 : (v >= 255.0f ? 255 : (unsigned char)v); }
 
 /* ---- compiled kernel bodies (symbols renamed per layout / file by the Makefile) ------------------ */
 typedef struct __attribute__((packed)) {
@@ -189,6 +196,12 @@ void __clang_ocl_kern_imp_circle(RefImage*, RefImage*, int);
 void __clang_ocl_kern_imp_matches(RefImage*, RefImage*, void*, volatile int*, float, float, int, int);
 void __clang_ocl_kern_imp_matches_score(RefImage*, RefImage*, RefImage*, float, int);
 void __clang_ocl_kern_imp_circularize(RefImage*, RefImage*, int, int);
+#define DECL_Q2R(L) void __clang_ocl_kern_imp_quad2rgba_##L(RefImage*, RefImage*, RefImage*, RefImage*, RefImage*)
+DECL_Q2R(RGGB); DECL_Q2R(GRBG); DECL_Q2R(BGR);
+#define DECL_Q2N(L) void __clang_ocl_kern_imp_quad2nv12_##L(RefImage*, RefImage*, RefImage*, RefImage*, unsigned char*)
+DECL_Q2N(RGGB); DECL_Q2N(GRBG); DECL_Q2N(BGR);
+void __clang_ocl_kern_imp_rgb2nv12(RefImage*, unsigned char*);
+void __clang_ocl_kern_imp_f2nv12(RefImage*, unsigned char*);
 
 #define NDRANGE_2D(W, H, CALL) \
 	do { g_gsize[0] = (W); g_gsize[1] = (H); \
@@ -257,4 +270,32 @@ void ref_blobscore(unsigned char* flat, float* circ, int w, int h, float* score,
 void ref_circularize(float* graddot, int w, int h, int minRadius, int maxRadius, float* out) {
 	RefImage i = mk(w, h, REF_FMT_F32, graddot), o = mk(w, h, REF_FMT_F32, out);
 	NDRANGE_2D(w, h, __clang_ocl_kern_imp_circularize(&i, &o, minRadius, maxRadius));
+}
+
+/* ---- debug / stream colour kernels (Resources.cpp:145-186).  The NV12 kernels let every pixel of a 2x2 block write the block's
+ * one UV pair (quad2nv12.cl:55-57, rgba2nv12.cl:28-30): a data race on a real device; this sequential raster execution
+ * resolves it as "the last pixel of the block in raster order wins". */
+void ref_quad2rgba(unsigned char* p0, unsigned char* p1, unsigned char* p2, unsigned char* p3, int qw, int qh, int layout, unsigned char* rgba) {
+	RefImage c0 = mk(qw, qh, REF_FMT_U8, p0), c1 = mk(qw, qh, REF_FMT_U8, p1), c2 = mk(qw, qh, REF_FMT_U8, p2), c3 = mk(qw, qh, REF_FMT_U8, p3);
+	RefImage out = mk(qw, qh, REF_FMT_RGBA8, rgba);
+	if(layout == 0) NDRANGE_2D(qw, qh, __clang_ocl_kern_imp_quad2rgba_RGGB(&c0, &c1, &c2, &c3, &out));
+	else if(layout == 1) NDRANGE_2D(qw, qh, __clang_ocl_kern_imp_quad2rgba_GRBG(&c0, &c1, &c2, &c3, &out));
+	else NDRANGE_2D(qw, qh, __clang_ocl_kern_imp_quad2rgba_BGR(&c0, &c1, &c2, &c3, &out));
+}
+
+void ref_quad2nv12(unsigned char* p0, unsigned char* p1, unsigned char* p2, unsigned char* p3, int qw, int qh, int layout, unsigned char* nv12) {
+	RefImage c0 = mk(qw, qh, REF_FMT_U8, p0), c1 = mk(qw, qh, REF_FMT_U8, p1), c2 = mk(qw, qh, REF_FMT_U8, p2), c3 = mk(qw, qh, REF_FMT_U8, p3);
+	if(layout == 0) NDRANGE_2D(qw, qh, __clang_ocl_kern_imp_quad2nv12_RGGB(&c0, &c1, &c2, &c3, nv12));
+	else if(layout == 1) NDRANGE_2D(qw, qh, __clang_ocl_kern_imp_quad2nv12_GRBG(&c0, &c1, &c2, &c3, nv12));
+	else NDRANGE_2D(qw, qh, __clang_ocl_kern_imp_quad2nv12_BGR(&c0, &c1, &c2, &c3, nv12));
+}
+
+void ref_rgba2nv12(unsigned char* rgba, int w, int h, unsigned char* nv12) {
+	RefImage in = mk(w, h, REF_FMT_RGBA8, rgba);
+	NDRANGE_2D(w, h, __clang_ocl_kern_imp_rgb2nv12(&in, nv12));
+}
+
+void ref_f2nv12(float* img, int w, int h, unsigned char* nv12) {
+	RefImage in = mk(w, h, REF_FMT_F32, img);
+	NDRANGE_2D(w, h, __clang_ocl_kern_imp_f2nv12(&in, nv12));
 }

@@ -427,6 +427,89 @@ void vpo_circularize(const float* graddot, int w, int h, int minRadius, int maxR
 	parallel_span(circz_rows, &c, h, threads);
 }
 
+/* ---------------------------------------------------------------- debug / stream colour kernels ------- */
+/* The colour of one quad-resolution pixel: quad2rgba.cl:27-50 == quad2nv12.cl:27-50.  BGR reads texel (x, y) itself
+ * (read_imageui with int2 coordinates); Bayer samples the four planes at (x +- 0.25, y +- 0.25) like resampling.cl:64-79,
+ * without the dRGB transform. */
+static inline void quad_colour(const uint8_t* const p[4], int qw, int qh, int layout, int mode, int x, int y, uint32_t* r, uint32_t* g, uint32_t* b) {
+	const float fx = (float)x, fy = (float)y;
+	if(layout == VPO_BGR) {
+		const size_t o = (size_t)y * qw + x;
+		*r = p[2][o];
+		*g = p[1][o];
+		*b = p[0][o];
+	} else if(layout == VPO_RGGB) {
+		*r = sample_u8(p[0], qw, qh, fx + 0.25f, fy + 0.25f, mode);
+		*g = sample_u8(p[1], qw, qh, fx - 0.25f, fy + 0.25f, mode) / 2 + sample_u8(p[2], qw, qh, fx + 0.25f, fy - 0.25f, mode) / 2;
+		*b = sample_u8(p[3], qw, qh, fx - 0.25f, fy - 0.25f, mode);
+	} else {
+		*r = sample_u8(p[1], qw, qh, fx - 0.25f, fy + 0.25f, mode);
+		*g = sample_u8(p[0], qw, qh, fx + 0.25f, fy + 0.25f, mode) / 2 + sample_u8(p[3], qw, qh, fx - 0.25f, fy - 0.25f, mode) / 2;
+		*b = sample_u8(p[2], qw, qh, fx + 0.25f, fy - 0.25f, mode);
+	}
+}
+static inline uint8_t sat_u8_u(uint32_t v) { return v > 255u ? 255 : (uint8_t)v; }
+static inline uint8_t sat_u8_i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v); }
+/* BT.601 limited range, integer (quad2nv12.cl:52,56-57 == rgba2nv12.cl:26,29-30): uint arithmetic for Y, int arithmetic with
+ * C division (truncation toward zero) for U and V */
+static inline uint8_t nv12_y(uint32_t r, uint32_t g, uint32_t b) { return sat_u8_u((66 * r + 129 * g + 25 * b) / 256 + 16); }
+static inline uint8_t nv12_u(uint32_t r, uint32_t g, uint32_t b) { return sat_u8_i((-38 * (int)r + -74 * (int)g + 112 * (int)b) / 256 + 128); }
+static inline uint8_t nv12_v(uint32_t r, uint32_t g, uint32_t b) { return sat_u8_i((112 * (int)r + -94 * (int)g + -18 * (int)b) / 256 + 128); }
+
+size_t vpo_nv12_bytes(int w, int h) { return (size_t)w * h + (size_t)w * ((h + 1) / 2); }
+
+/* quad2rgba.cl:24-53 */
+void vpo_quad2rgba(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3, int qw, int qh, int layout, int sampler_mode, uint8_t* rgba) {
+	const uint8_t* const p[4] = {p0, p1, p2, p3};
+	for(int y = 0; y < qh; y++)
+		for(int x = 0; x < qw; x++) {
+			uint32_t r, g, b;
+			quad_colour(p, qw, qh, layout, sampler_mode, x, y, &r, &g, &b);
+			uint8_t* o = rgba + 4 * ((size_t)y * qw + x);
+			o[0] = sat_u8_u(r);
+			o[1] = sat_u8_u(g);
+			o[2] = sat_u8_u(b);
+			o[3] = 255;
+		}
+}
+
+/* quad2nv12.cl:24-58.  Every pixel writes its Y; every pixel also writes the UV pair of its 2x2 block (:54-57), so on a
+ * device the four writers race.  Raster-sequential execution: the last pixel of the block in raster order wins. */
+void vpo_quad2nv12(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3, int qw, int qh, int layout, int sampler_mode, uint8_t* nv12) {
+	const uint8_t* const p[4] = {p0, p1, p2, p3};
+	for(int y = 0; y < qh; y++)
+		for(int x = 0; x < qw; x++) {
+			uint32_t r, g, b;
+			quad_colour(p, qw, qh, layout, sampler_mode, x, y, &r, &g, &b);
+			nv12[(size_t)x + (size_t)y * qw] = nv12_y(r, g, b);
+			const size_t uv = (size_t)qw * qh + (size_t)(x / 2) * 2 + (size_t)(y / 2) * qw;
+			nv12[uv] = nv12_u(r, g, b);
+			nv12[uv + 1] = nv12_v(r, g, b);
+		}
+}
+
+/* rgba2nv12.cl:22-31 (kernel name rgb2nv12) */
+void vpo_rgba2nv12(const uint8_t* rgba, int w, int h, uint8_t* nv12) {
+	for(int y = 0; y < h; y++)
+		for(int x = 0; x < w; x++) {
+			const uint8_t* v = rgba + 4 * ((size_t)y * w + x);
+			nv12[(size_t)x + (size_t)y * w] = nv12_y(v[0], v[1], v[2]);
+			const size_t uv = (size_t)w * h + (size_t)(x / 2) * 2 + (size_t)(y / 2) * w;
+			nv12[uv] = nv12_u(v[0], v[1], v[2]);
+			nv12[uv + 1] = nv12_v(v[0], v[1], v[2]);
+		}
+}
+
+/* f2nv12.cl:22-26: Y = convert_uchar_sat(value + 127) (round toward zero, NaN -> 0), chroma 127 */
+void vpo_f2nv12(const float* img, int w, int h, uint8_t* nv12) {
+	for(int y = 0; y < h; y++)
+		for(int x = 0; x < w; x++) {
+			const float v = img[(size_t)y * w + x] + 127;
+			nv12[(size_t)x + (size_t)y * w] = !(v > 0.0f) ? 0 : (v >= 255.0f ? 255 : (uint8_t)v);
+			nv12[(size_t)w * h + (size_t)x + (size_t)(y / 2) * w] = 127;
+		}
+}
+
 /* ---------------------------------------------------------------- host readback ---------------------- */
 void vpo_flat2field(float x, float y, float fieldScale, float extX, float extY, float* fx, float* fy) {
 	*fx = x * fieldScale + extX; /* Perspective.cpp:127-129 */

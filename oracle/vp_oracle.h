@@ -17,6 +17,7 @@
  */
 #ifndef VP_ORACLE_H
 #define VP_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -79,6 +80,18 @@ void vpo_blobscore(const uint8_t* flat, const float* circ, int w, int h, float c
 /* blobCenter.cl:29-63 (never compiled by the reference) */
 void vpo_circularize(const float* graddot, int w, int h, int minRadius, int maxRadius, float* out, int threads);
 
+/* Debug / stream colour kernels (Resources.cpp:145-186).  NV12 buffers are w*h luma bytes followed by
+ * ceil(h/2) rows of w interleaved U,V bytes (vpo_nv12_bytes); w must be even.  The reference lets all four pixels of a 2x2
+ * block write the block's UV pair (a race): here the last pixel of the block in raster order wins. */
+size_t vpo_nv12_bytes(int w, int h);
+/* quad2rgba.cl:24-53 */
+void vpo_quad2rgba(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3, int qw, int qh, int layout, int sampler_mode, uint8_t* rgba);
+/* quad2nv12.cl:24-58 */
+void vpo_quad2nv12(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3, int qw, int qh, int layout, int sampler_mode, uint8_t* nv12);
+/* rgba2nv12.cl:22-31 */
+void vpo_rgba2nv12(const uint8_t* rgba, int w, int h, uint8_t* nv12);
+/* f2nv12.cl:22-26 */
+void vpo_f2nv12(const float* img, int w, int h, uint8_t* nv12);
 /* Perspective.cpp:127-129 */
 void vpo_flat2field(float x, float y, float fieldScale, float extX, float extY, float* fx, float* fy);
 

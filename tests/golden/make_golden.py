@@ -49,6 +49,13 @@ def main():
             planes=planes, flat=flat, graddot=exact_i32(ch["graddot"], "graddot"), sat=exact_i32(ch["sat"], "sat"), blobcenter=ch["blobcenter"],
             matches=np.frombuffer(ch["matches"].tobytes(), np.uint8), idx=ch["idx"], counter=ch["counter"], max_abs_sat=np.float64(max_sat),
         )
+        # debug / stream colour kernels: quad2rgba, quad2nv12, rgb2nv12, f2nv12 (NV12 needs an even width)
+        out["quad_rgba"] = ref.quad2rgba(planes, cfg.layout, mode)
+        if cfg.qw % 2 == 0:
+            out["quad_nv12"] = ref.quad2nv12(planes, cfg.layout, mode)
+        if cfg.fw % 2 == 0:
+            out["flat_nv12"] = ref.rgba2nv12(flat)
+            out["blobcenter_nv12"] = ref.f2nv12(ch["blobcenter"])
         if cfg is cases.cfgs.T_BGR and mode == 1:
             # the two kernels the reference names but never launches: blobScore.cl, blobCenter.cl
             out["blobscore"] = ref.blobscore(flat, ch["blobcenter"], cfg.circ_threshold, cfg.list_radius)

@@ -244,6 +244,70 @@ def test_resample_mapped_batches(gpu, port, cfg, B, mode):
         assert np.array_equal(got[i], want), f"frame {i}"
 
 
+@pytest.mark.parametrize("cfg,mode,seed", cases.CHAIN_CASES, ids=[cases.chain_case_name(*c) for c in cases.CHAIN_CASES])
+def test_golden_colour_kernels(gpu, cfg, mode, seed):
+    """Debug / stream colour kernels through the C ABI against the golden vectors."""
+    capi, ctx, torch = gpu
+    g = cases.load_golden(cases.chain_case_name(cfg, mode, seed))
+    qw, qh, fw, fh, layout = int(g["qw"]), int(g["qh"]), int(g["fw"]), int(g["fh"]), int(g["layout"])
+    d_planes, d_raw = dev(torch, g["planes"]), dev(torch, g["raw"])
+    d_rgba = torch.zeros((qh, qw, 4), dtype=torch.uint8, device="cuda")
+    ctx.quad2rgba(d_planes, layout, qw, qh, mode, 1, d_rgba)
+    assert np.array_equal(host(d_rgba), g["quad_rgba"])
+    d_rgba.zero_()
+    ctx.raw2rgba(d_raw, layout, qw, qh, mode, 1, d_rgba)
+    assert np.array_equal(host(d_rgba), g["quad_rgba"]), "fused raw2quad+quad2rgba"
+    d_rgba.zero_()
+    pl = [d_planes[i] for i in range(4)]
+    ctx.quad2rgba4(pl[0], pl[1], pl[2], pl[3] if layout != cfgs.BGR else None, layout, qw, qh, mode, d_rgba)
+    assert np.array_equal(host(d_rgba), g["quad_rgba"]), "separately allocated planes"
+    if "quad_nv12" in g:
+        assert ctx.nv12_bytes(qw, qh) == g["quad_nv12"].size
+        for fn, src in ((ctx.quad2nv12, d_planes), (ctx.raw2nv12, d_raw)):
+            d_nv = torch.full((g["quad_nv12"].size,), 0xEE, dtype=torch.uint8, device="cuda")
+            fn(src, layout, qw, qh, mode, 1, d_nv)
+            assert np.array_equal(host(d_nv), g["quad_nv12"]), fn.__name__
+    else:
+        with pytest.raises(capi.VpError):
+            ctx.quad2nv12(d_planes, layout, qw, qh, mode, 1, torch.zeros(ctx.nv12_bytes(qw, qh), dtype=torch.uint8, device="cuda"))  # odd width is refused
+    if "flat_nv12" in g:
+        d_nv = torch.full((g["flat_nv12"].size,), 0xEE, dtype=torch.uint8, device="cuda")
+        ctx.rgba2nv12(dev(torch, g["flat"]), fw, fh, 1, d_nv)
+        assert np.array_equal(host(d_nv), g["flat_nv12"])
+        d_nv.fill_(0xEE)
+        ctx.f2nv12(dev(torch, g["blobcenter"]), fw, fh, 1, d_nv)
+        assert np.array_equal(host(d_nv), g["blobcenter_nv12"])
+
+
+def test_colour_kernels_batches_and_odd_heights(gpu, port):
+    """Batched launches, odd heights (last chroma row owned by a single luma row), special floats; live against the CPU oracle."""
+    capi, ctx, torch = gpu
+    rng = np.random.default_rng(5)
+    B, qw, qh = 3, 70, 37
+    planes = rng.integers(0, 256, (B, 4, qh, qw), dtype=np.uint8)
+    d_planes = dev(torch, planes)
+    nb = ctx.nv12_bytes(qw, qh)
+    for layout in (cfgs.RGGB, cfgs.GRBG, cfgs.BGR):
+        for mode in (0, 1):
+            d_rgba = torch.zeros((B, qh, qw, 4), dtype=torch.uint8, device="cuda")
+            d_nv = torch.zeros((B, nb), dtype=torch.uint8, device="cuda")
+            ctx.quad2rgba(d_planes, layout, qw, qh, mode, B, d_rgba)
+            ctx.quad2nv12(d_planes, layout, qw, qh, mode, B, d_nv)
+            for i in range(B):
+                assert np.array_equal(host(d_rgba[i]), port.quad2rgba(planes[i], layout, mode)), (layout, mode, i)
+                assert np.array_equal(host(d_nv[i]), port.quad2nv12(planes[i], layout, mode)), (layout, mode, i)
+    rgba = rng.integers(0, 256, (B, qh, qw, 4), dtype=np.uint8)
+    f = (rng.standard_normal((B, qh, qw)) * 200).astype(np.float32)
+    f[0, 0, :6] = [np.nan, np.inf, -np.inf, 127.999, -127.0, 128.0]
+    d_nv = torch.zeros((B, nb), dtype=torch.uint8, device="cuda")
+    ctx.rgba2nv12(dev(torch, rgba), qw, qh, B, d_nv)
+    for i in range(B):
+        assert np.array_equal(host(d_nv[i]), port.rgba2nv12(rgba[i]))
+    ctx.f2nv12(dev(torch, f), qw, qh, B, d_nv)
+    for i in range(B):
+        assert np.array_equal(host(d_nv[i]), port.f2nv12(f[i]))
+
+
 def test_full_size_properties(gpu, port):
     """BASELINE.json configs[1] (2048x1536): properties that do not need a full CPU reference run per frame."""
     capi, ctx, torch = gpu

@@ -41,6 +41,13 @@ def test_chain_stages_bit_exact(port, cfg, mode, seed):
     assert np.array_equal(cnt, g["counter"])
     assert np.array_equal(idx, g["idx"])
     assert m.tobytes() == g["matches"].tobytes()
+    # debug / stream colour kernels
+    assert np.array_equal(port.quad2rgba(g["planes"], int(g["layout"]), smode), g["quad_rgba"])
+    if "quad_nv12" in g:
+        assert np.array_equal(port.quad2nv12(g["planes"], int(g["layout"]), smode), g["quad_nv12"])
+    if "flat_nv12" in g:
+        assert np.array_equal(port.rgba2nv12(g["flat"]), g["flat_nv12"])
+        assert np.array_equal(port.f2nv12(g["blobcenter"]), g["blobcenter_nv12"])
     if "blobscore" in g:
         assert np.array_equal(port.blobscore(g["flat"], g["blobcenter"], thr, R), g["blobscore"])
         assert np.array_equal(port.circularize(gd, R, r), g["circularize"], equal_nan=True)

@@ -57,3 +57,21 @@ def test_threads_do_not_change_results(port):
     assert m1.tobytes() == m4.tobytes() and np.array_equal(i1, i4) and np.array_equal(c1, c4)
     m5, i5, c5 = port.frame(*args, sat_mode=1)  # int32 SAT path gives the same list under the guard
     assert m1.tobytes() == m5.tobytes() and np.array_equal(c1, c5)
+
+
+@pytest.mark.parametrize("shape", [(16, 12), (18, 7), (6, 5), (64, 33)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_colour_kernels_port_equals_reference(port, ref, shape):
+    """quad2rgba / quad2nv12 / rgb2nv12 / f2nv12: all layouts, both sampler modes, odd heights, NaN / inf / saturating floats."""
+    qw, qh = shape
+    rng = np.random.default_rng(qw * 100 + qh)
+    planes = rng.integers(0, 256, (4, qh, qw), dtype=np.uint8)
+    for layout in (cfgs.RGGB, cfgs.GRBG, cfgs.BGR):
+        for mode in (0, 1):
+            assert np.array_equal(port.quad2rgba(planes, layout, mode), ref.quad2rgba(planes, layout, mode)), (layout, mode)
+            assert np.array_equal(port.quad2nv12(planes, layout, mode), ref.quad2nv12(planes, layout, mode)), (layout, mode)
+    rgba = rng.integers(0, 256, (qh, qw, 4), dtype=np.uint8)
+    rgba[0, :4] = [[255, 0, 0, 255], [0, 255, 0, 255], [0, 0, 255, 255], [255, 255, 255, 255]]  # chroma extremes
+    assert np.array_equal(port.rgba2nv12(rgba), ref.rgba2nv12(rgba))
+    f = (rng.standard_normal((qh, qw)) * 200).astype(np.float32)
+    f[0, :6] = [np.nan, np.inf, -np.inf, 127.999, -127.0, 128.0]
+    assert np.array_equal(port.f2nv12(f), ref.f2nv12(f))

@@ -180,6 +180,35 @@ class Context:
     def resample_raw(self, raw, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream=0):
         self._resample(self.l.vp_resample_raw, raw, layout, qw, qh, model, height, fs, ox, oy, mode, fw, fh, batch, flat, stream)
 
+    # ---- debug / stream colour kernels
+    def nv12_bytes(self, w, h):
+        self.l.vp_nv12_bytes.restype = C.c_size_t
+        return int(self.l.vp_nv12_bytes(int(w), int(h)))
+
+    def quad2rgba(self, planes, layout, qw, qh, mode, batch, rgba, stream=0):
+        self._ck(self.l.vp_quad2rgba(self.h, stream, _ptr(planes), int(layout), int(qw), int(qh), int(mode), int(batch), _ptr(rgba)))
+
+    def raw2rgba(self, raw, layout, qw, qh, mode, batch, rgba, stream=0):
+        self._ck(self.l.vp_raw2rgba(self.h, stream, _ptr(raw), int(layout), int(qw), int(qh), int(mode), int(batch), _ptr(rgba)))
+
+    def quad2nv12(self, planes, layout, qw, qh, mode, batch, nv12, stream=0):
+        self._ck(self.l.vp_quad2nv12(self.h, stream, _ptr(planes), int(layout), int(qw), int(qh), int(mode), int(batch), _ptr(nv12)))
+
+    def raw2nv12(self, raw, layout, qw, qh, mode, batch, nv12, stream=0):
+        self._ck(self.l.vp_raw2nv12(self.h, stream, _ptr(raw), int(layout), int(qw), int(qh), int(mode), int(batch), _ptr(nv12)))
+
+    def quad2rgba4(self, p0, p1, p2, p3, layout, qw, qh, mode, rgba, stream=0):
+        self._ck(self.l.vp_quad2rgba4(self.h, stream, _ptr(p0), _ptr(p1), _ptr(p2), _ptr(p3), int(layout), int(qw), int(qh), int(mode), _ptr(rgba)))
+
+    def quad2nv124(self, p0, p1, p2, p3, layout, qw, qh, mode, nv12, stream=0):
+        self._ck(self.l.vp_quad2nv124(self.h, stream, _ptr(p0), _ptr(p1), _ptr(p2), _ptr(p3), int(layout), int(qw), int(qh), int(mode), _ptr(nv12)))
+
+    def rgba2nv12(self, rgba, w, h, batch, nv12, stream=0):
+        self._ck(self.l.vp_rgba2nv12(self.h, stream, _ptr(rgba), int(w), int(h), int(batch), _ptr(nv12)))
+
+    def f2nv12(self, img, w, h, batch, nv12, stream=0):
+        self._ck(self.l.vp_f2nv12(self.h, stream, _ptr(img), int(w), int(h), int(batch), _ptr(nv12)))
+
     def resample_map(self, model, height, fs, ox, oy, fw, fh, map_out, stream=0):
         self._ck(self.l.vp_resample_map(self.h, stream, C.byref(model), C.c_float(height), C.c_float(fs), C.c_float(ox), C.c_float(oy), int(fw), int(fh), _ptr(map_out)))
 

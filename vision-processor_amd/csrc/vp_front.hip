@@ -674,3 +674,196 @@ extern "C" int vp_resample_raw(VpContext* ctx, int stream, const uint8_t* raw, i
 		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat) {
 	return resample_dispatch<true>(ctx, stream, raw, nullptr, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, batch, flat, "raw2quad+resampling");
 }
+
+// ---------------------------------------------------------------- debug / stream colour kernels ----------
+// quad2rgba.cl:24-53, quad2nv12.cl:24-58, rgba2nv12.cl:22-31, f2nv12.cl:22-26 (Resources.cpp:145-149, 166-186).
+// NV12 frame: w*h luma bytes, then ceil(h/2) rows of w interleaved U,V bytes.  In the reference all four pixels of a 2x2 block
+// store the block's UV pair (a race); here ONE thread owns a 2x2 block and stores the value of its last pixel in raster order,
+// which is what sequential execution of the reference produces (the oracle's definition).
+
+// colour of quad pixel (x, y): quad2rgba.cl:27-50.  BGR reads the texel itself (int2 coordinates), Bayer samples at +-0.25.
+template<int LAYOUT, int MODE, bool FROM_RAW>
+__device__ __forceinline__ void quad_colour(const Src& s, int x, int y, int qw, int qh, uint32_t& r, uint32_t& g, uint32_t& b) {
+	const float fx = (float)x, fy = (float)y;
+	if(LAYOUT == VP_LAYOUT_BGR) {
+		r = texel<LAYOUT, FROM_RAW>(s, 2, x, y, qw, qh);
+		g = texel<LAYOUT, FROM_RAW>(s, 1, x, y, qw, qh);
+		b = texel<LAYOUT, FROM_RAW>(s, 0, x, y, qw, qh);
+	} else if(LAYOUT == VP_LAYOUT_RGGB) {
+		r = sample<LAYOUT, MODE, FROM_RAW>(s, 0, fx + 0.25f, fy + 0.25f, qw, qh);
+		g = sample<LAYOUT, MODE, FROM_RAW>(s, 1, fx - 0.25f, fy + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, FROM_RAW>(s, 2, fx + 0.25f, fy - 0.25f, qw, qh) / 2;
+		b = sample<LAYOUT, MODE, FROM_RAW>(s, 3, fx - 0.25f, fy - 0.25f, qw, qh);
+	} else {
+		r = sample<LAYOUT, MODE, FROM_RAW>(s, 1, fx - 0.25f, fy + 0.25f, qw, qh);
+		g = sample<LAYOUT, MODE, FROM_RAW>(s, 0, fx + 0.25f, fy + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, FROM_RAW>(s, 3, fx - 0.25f, fy - 0.25f, qw, qh) / 2;
+		b = sample<LAYOUT, MODE, FROM_RAW>(s, 2, fx + 0.25f, fy - 0.25f, qw, qh);
+	}
+}
+
+// BT.601 limited range in integers (quad2nv12.cl:52,56-57): Y in uint arithmetic, U/V in int arithmetic with truncating division
+__device__ __forceinline__ uint32_t nv12_y(uint32_t r, uint32_t g, uint32_t b) { return min((66u * r + 129u * g + 25u * b) / 256u + 16u, 255u); }
+__device__ __forceinline__ uint32_t nv12_u(uint32_t r, uint32_t g, uint32_t b) { return (uint32_t)vp_clampi((-38 * (int)r - 74 * (int)g + 112 * (int)b) / 256 + 128, 0, 255); }
+__device__ __forceinline__ uint32_t nv12_v(uint32_t r, uint32_t g, uint32_t b) { return (uint32_t)vp_clampi((112 * (int)r - 94 * (int)g - 18 * (int)b) / 256 + 128, 0, 255); }
+
+extern "C" size_t vp_nv12_bytes(int w, int h) { return w > 0 && h > 0 ? (size_t)w * h + (size_t)w * ((h + 1) / 2) : 0; }
+
+struct QuadSrcArgs {
+	const uint8_t* raw;  // FROM_RAW: batch x frame_bytes
+	const uint8_t* pl[4]; // planes
+	size_t bstride;      // bytes between frames (raw: frame bytes; planes: 4*qw*qh or 0 for separately allocated planes)
+};
+
+template<int LAYOUT, int MODE, bool FROM_RAW>
+__global__ __launch_bounds__(256) void k_quad2rgba(const QuadSrcArgs a, uint32_t* __restrict__ rgba, int qw, int qh) {
+	const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+	if(x >= qw || y >= qh) return;
+	Src s;
+	s.raw = a.raw + (size_t)blockIdx.z * a.bstride;
+#pragma unroll
+	for(int c = 0; c < 4; c++) s.p[c] = a.pl[c] + (size_t)blockIdx.z * a.bstride;
+	uint32_t r, g, b;
+	quad_colour<LAYOUT, MODE, FROM_RAW>(s, x, y, qw, qh, r, g, b);
+	rgba[(size_t)blockIdx.z * qw * qh + (size_t)y * qw + x] = r | (g << 8) | (b << 16) | 0xFF000000u; // channels are bytes: write_imageui cannot saturate
+}
+
+// one thread per 2x2 block (w even): two 2-byte luma stores, one 2-byte chroma store
+template<int LAYOUT, int MODE, bool FROM_RAW>
+__global__ __launch_bounds__(256) void k_quad2nv12(const QuadSrcArgs a, uint8_t* __restrict__ nv12, int qw, int qh, size_t out_stride) {
+	const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+	if(2 * bx >= qw || 2 * by >= qh) return;
+	Src s;
+	s.raw = a.raw + (size_t)blockIdx.z * a.bstride;
+#pragma unroll
+	for(int c = 0; c < 4; c++) s.p[c] = a.pl[c] + (size_t)blockIdx.z * a.bstride;
+	uint8_t* out = nv12 + (size_t)blockIdx.z * out_stride;
+	uint32_t r = 0, g = 0, b = 0;
+#pragma unroll
+	for(int dy = 0; dy < 2; dy++) {
+		const int y = 2 * by + dy;
+		if(y >= qh) break;
+		uint32_t r0, g0, b0;
+		quad_colour<LAYOUT, MODE, FROM_RAW>(s, 2 * bx, y, qw, qh, r0, g0, b0);
+		quad_colour<LAYOUT, MODE, FROM_RAW>(s, 2 * bx + 1, y, qw, qh, r, g, b); // the last one evaluated is the block's last pixel in raster order
+		*reinterpret_cast<uint16_t*>(out + (size_t)y * qw + 2 * bx) = (uint16_t)(nv12_y(r0, g0, b0) | (nv12_y(r, g, b) << 8));
+	}
+	*reinterpret_cast<uint16_t*>(out + (size_t)qw * qh + (size_t)by * qw + 2 * bx) = (uint16_t)(nv12_u(r, g, b) | (nv12_v(r, g, b) << 8));
+}
+
+__global__ __launch_bounds__(256) void k_rgba2nv12(const uint32_t* __restrict__ rgba, uint8_t* __restrict__ nv12, int w, int h, size_t out_stride) {
+	const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+	if(2 * bx >= w || 2 * by >= h) return;
+	const uint32_t* in = rgba + (size_t)blockIdx.z * w * h;
+	uint8_t* out = nv12 + (size_t)blockIdx.z * out_stride;
+	uint32_t last = 0;
+#pragma unroll
+	for(int dy = 0; dy < 2; dy++) {
+		const int y = 2 * by + dy;
+		if(y >= h) break;
+		const uint2 v = *reinterpret_cast<const uint2*>(in + (size_t)y * w + 2 * bx);
+		last = v.y;
+		*reinterpret_cast<uint16_t*>(out + (size_t)y * w + 2 * bx) =
+				(uint16_t)(nv12_y(v.x & 0xFF, (v.x >> 8) & 0xFF, (v.x >> 16) & 0xFF) | (nv12_y(v.y & 0xFF, (v.y >> 8) & 0xFF, (v.y >> 16) & 0xFF) << 8));
+	}
+	const uint32_t r = last & 0xFF, g = (last >> 8) & 0xFF, b = (last >> 16) & 0xFF;
+	*reinterpret_cast<uint16_t*>(out + (size_t)w * h + (size_t)by * w + 2 * bx) = (uint16_t)(nv12_u(r, g, b) | (nv12_v(r, g, b) << 8));
+}
+
+// convert_uchar_sat(float): round toward zero, saturate, NaN -> 0 (OpenCL C 6.4.3)
+__device__ __forceinline__ uint32_t f2u8_sat(float v) { return !(v > 0.0f) ? 0u : (v >= 255.0f ? 255u : (uint32_t)v); }
+
+__global__ __launch_bounds__(256) void k_f2nv12(const float* __restrict__ img, uint8_t* __restrict__ nv12, int w, int h, size_t out_stride) {
+	const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+	if(2 * bx >= w || 2 * by >= h) return;
+	const float* in = img + (size_t)blockIdx.z * w * h;
+	uint8_t* out = nv12 + (size_t)blockIdx.z * out_stride;
+#pragma unroll
+	for(int dy = 0; dy < 2; dy++) {
+		const int y = 2 * by + dy;
+		if(y >= h) break;
+		const float2 v = *reinterpret_cast<const float2*>(in + (size_t)y * w + 2 * bx);
+		*reinterpret_cast<uint16_t*>(out + (size_t)y * w + 2 * bx) = (uint16_t)(f2u8_sat(v.x + 127) | (f2u8_sat(v.y + 127) << 8)); // f2nv12.cl:24
+	}
+	*reinterpret_cast<uint16_t*>(out + (size_t)w * h + (size_t)by * w + 2 * bx) = 0x7F7F; // :25
+}
+
+template<bool FROM_RAW, bool NV12>
+static int quad_colour_dispatch(VpContext* ctx, int stream, const uint8_t* src, const uint8_t* const* planes4, int layout, int qw, int qh, int mode, int batch, uint8_t* out,
+		const char* name) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE((src || planes4) && out && qw > 0 && qh > 0 && batch > 0 && batch <= 65535, "%s: bad arguments", name);
+	VP_REQUIRE(layout >= 0 && layout <= 2 && (mode == VP_SAMPLER_NEAREST || mode == VP_SAMPLER_BILINEAR_RTZ), "%s: bad layout/sampler mode", name);
+	VP_REQUIRE(!NV12 || (qw & 1) == 0, "%s: NV12 needs an even width", name);
+	VP_REQUIRE(NV12 ? (reinterpret_cast<uintptr_t>(out) & 1) == 0 : (reinterpret_cast<uintptr_t>(out) & 3) == 0, "%s: misaligned output", name);
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, name);
+	const size_t q = (size_t)qw * qh;
+	QuadSrcArgs a;
+	a.raw = FROM_RAW ? src : nullptr;
+	for(int c = 0; c < 4; c++) a.pl[c] = FROM_RAW ? nullptr : (planes4 ? planes4[c] : src + c * q);
+	a.bstride = FROM_RAW ? (layout == VP_LAYOUT_BGR ? 3 * q : 4 * q) : (planes4 ? 0 : 4 * q);
+	hipStream_t s = ctx->streams[stream];
+	const dim3 block(64, 4);
+	const dim3 grid(NV12 ? vp_div_up((qw + 1) / 2, 64) : vp_div_up(qw, 64), NV12 ? vp_div_up((qh + 1) / 2, 4) : vp_div_up(qh, 4), batch);
+	const size_t ostride = vp_nv12_bytes(qw, qh);
+#define VP_QC(L, M) \
+	do { \
+		if(NV12) k_quad2nv12<L, M, FROM_RAW><<<grid, block, 0, s>>>(a, out, qw, qh, ostride); \
+		else k_quad2rgba<L, M, FROM_RAW><<<grid, block, 0, s>>>(a, reinterpret_cast<uint32_t*>(out), qw, qh); \
+	} while(0)
+	if(mode == VP_SAMPLER_NEAREST) {
+		if(layout == VP_LAYOUT_RGGB) VP_QC(VP_LAYOUT_RGGB, VP_SAMPLER_NEAREST);
+		else if(layout == VP_LAYOUT_GRBG) VP_QC(VP_LAYOUT_GRBG, VP_SAMPLER_NEAREST);
+		else VP_QC(VP_LAYOUT_BGR, VP_SAMPLER_NEAREST);
+	} else {
+		if(layout == VP_LAYOUT_RGGB) VP_QC(VP_LAYOUT_RGGB, VP_SAMPLER_BILINEAR_RTZ);
+		else if(layout == VP_LAYOUT_GRBG) VP_QC(VP_LAYOUT_GRBG, VP_SAMPLER_BILINEAR_RTZ);
+		else VP_QC(VP_LAYOUT_BGR, VP_SAMPLER_BILINEAR_RTZ);
+	}
+#undef VP_QC
+	return vp_launch_ok(name);
+}
+
+extern "C" int vp_quad2rgba(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* rgba) {
+	return quad_colour_dispatch<false, false>(ctx, stream, planes, nullptr, layout, qw, qh, sampler_mode, batch, rgba, "quad2rgba");
+}
+extern "C" int vp_quad2rgba4(VpContext* ctx, int stream, const uint8_t* plane0, const uint8_t* plane1, const uint8_t* plane2, const uint8_t* plane3, int layout, int qw, int qh,
+		int sampler_mode, uint8_t* rgba) {
+	VP_REQUIRE(plane0 && plane1 && plane2 && (plane3 || layout == VP_LAYOUT_BGR), "vp_quad2rgba4: null plane");
+	const uint8_t* pl[4] = {plane0, plane1, plane2, plane3 ? plane3 : plane2};
+	return quad_colour_dispatch<false, false>(ctx, stream, nullptr, pl, layout, qw, qh, sampler_mode, 1, rgba, "quad2rgba");
+}
+extern "C" int vp_raw2rgba(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* rgba) {
+	return quad_colour_dispatch<true, false>(ctx, stream, raw, nullptr, layout, qw, qh, sampler_mode, batch, rgba, "raw2quad+quad2rgba");
+}
+extern "C" int vp_quad2nv12(VpContext* ctx, int stream, const uint8_t* planes, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* nv12) {
+	return quad_colour_dispatch<false, true>(ctx, stream, planes, nullptr, layout, qw, qh, sampler_mode, batch, nv12, "quad2nv12");
+}
+extern "C" int vp_quad2nv124(VpContext* ctx, int stream, const uint8_t* plane0, const uint8_t* plane1, const uint8_t* plane2, const uint8_t* plane3, int layout, int qw, int qh,
+		int sampler_mode, uint8_t* nv12) {
+	VP_REQUIRE(plane0 && plane1 && plane2 && (plane3 || layout == VP_LAYOUT_BGR), "vp_quad2nv124: null plane");
+	const uint8_t* pl[4] = {plane0, plane1, plane2, plane3 ? plane3 : plane2};
+	return quad_colour_dispatch<false, true>(ctx, stream, nullptr, pl, layout, qw, qh, sampler_mode, 1, nv12, "quad2nv12");
+}
+extern "C" int vp_raw2nv12(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, int sampler_mode, int batch, uint8_t* nv12) {
+	return quad_colour_dispatch<true, true>(ctx, stream, raw, nullptr, layout, qw, qh, sampler_mode, batch, nv12, "raw2quad+quad2nv12");
+}
+
+extern "C" int vp_rgba2nv12(VpContext* ctx, int stream, const uint8_t* rgba, int w, int h, int batch, uint8_t* nv12) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(rgba && nv12 && w > 0 && h > 0 && batch > 0 && batch <= 65535, "vp_rgba2nv12: bad arguments");
+	VP_REQUIRE((w & 1) == 0 && (reinterpret_cast<uintptr_t>(rgba) & 7) == 0 && (reinterpret_cast<uintptr_t>(nv12) & 1) == 0, "vp_rgba2nv12: needs an even width, 8-byte aligned input");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "rgba2nv12");
+	k_rgba2nv12<<<dim3(vp_div_up(w / 2, 64), vp_div_up((h + 1) / 2, 4), batch), dim3(64, 4), 0, ctx->streams[stream]>>>(reinterpret_cast<const uint32_t*>(rgba), nv12, w, h, vp_nv12_bytes(w, h));
+	return vp_launch_ok("rgba2nv12");
+}
+
+extern "C" int vp_f2nv12(VpContext* ctx, int stream, const float* img, int w, int h, int batch, uint8_t* nv12) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(img && nv12 && w > 0 && h > 0 && batch > 0 && batch <= 65535, "vp_f2nv12: bad arguments");
+	VP_REQUIRE((w & 1) == 0 && (reinterpret_cast<uintptr_t>(img) & 7) == 0 && (reinterpret_cast<uintptr_t>(nv12) & 1) == 0, "vp_f2nv12: needs an even width, 8-byte aligned input");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "f2nv12");
+	k_f2nv12<<<dim3(vp_div_up(w / 2, 64), vp_div_up((h + 1) / 2, 4), batch), dim3(64, 4), 0, ctx->streams[stream]>>>(img, nv12, w, h, vp_nv12_bytes(w, h));
+	return vp_launch_ok("f2nv12");
+}
