@@ -15,7 +15,7 @@ cfgs = cases.cfgs
 BIN = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_frame_loop")
 
 
-def run_loop(cfg, frames, seed, mode, tmp_path):
+def run_loop(cfg, frames, seed, mode, tmp_path, debug_dump=None):
     dump = str(tmp_path / f"{cfg.name}_{mode}.bin")
     args = [BIN, str(cfg.layout), str(cfg.qw), str(cfg.qh), str(cfg.cam_height), str(cfg.visible_len), str(cfg.distortion), str(cfg.field_len), str(cfg.field_wid),
             str(frames), str(0x5EED0000 + seed), str(cfg.n_robots), str(cfg.n_balls), mode]
@@ -24,6 +24,8 @@ def run_loop(cfg, frames, seed, mode, tmp_path):
     args.append(dump)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    if debug_dump:
+        env["VP_DEBUG_DUMP"] = debug_dump
     out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     recs = []
@@ -72,3 +74,28 @@ def test_frame_loop_geometry_check(port, tmp_path):
     # 3000 mm of the plane over 320 quad pixels, distortion shrinks the footprint a little: ~9-10 mm per quad pixel
     assert 8.0 < r["fs"] < 11.0 and r["fw"] % 2 == 0 and r["fh"] % 2 == 0
     check_against_oracle(port, cfg, recs, 60)
+
+
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.CFG1], ids=lambda c: c.name)
+def test_debug_and_stream_views(port, cfg, tmp_path):
+    """Resources::quad2rgba / streamQuad / streamImage (Resources.cpp:145-186) through the facade: the RGBA view and the three NV12
+    frames of the first frame (main.cpp:291,377-403) against the CPU oracle."""
+    dbg = str(tmp_path / "debug.bin")
+    recs, _ = run_loop(cfg, 1, 70, "direct", tmp_path, debug_dump=dbg)
+    bufs = []
+    with open(dbg, "rb") as f:
+        while True:
+            n = f.read(8)
+            if len(n) < 8:
+                break
+            bufs.append(np.frombuffer(f.read(struct.unpack("Q", n)[0]), np.uint8))
+    assert len(bufs) == 4
+    raw = cfg.synth(70)
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    planes = port.raw2quad(raw, cfg.layout, cfg.qw, cfg.qh)
+    flat = port.resample(planes, cfg.layout, model, 180.0, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh)
+    bc = port.blobcenter(port.sat(port.graddot(flat, cfg.grad_offset)), cfg.circle_radius)
+    assert np.array_equal(bufs[0].reshape(cfg.qh, cfg.qw, 4), port.quad2rgba(planes, cfg.layout, 1))
+    assert np.array_equal(bufs[1], port.quad2nv12(planes, cfg.layout, 1))
+    assert np.array_equal(bufs[2], port.rgba2nv12(flat))
+    assert np.array_equal(bufs[3], port.f2nv12(bc))

@@ -22,6 +22,10 @@ Resources::Resources(std::unique_ptr<SyntheticCamera> cam, int camId, float geom
 	satHorizontal = openCl->compile(kernel_satHorizontal_cl);
 	satVertical = openCl->compile(kernel_satVertical_cl);
 	satBlobCenter = openCl->compile(kernel_satBlobCenter_cl);
+	quad2rgbaKernel = openCl->compile(kernel_quad2rgba_cl, layout);
+	quad2nv12 = openCl->compile(kernel_quad2nv12_cl, layout);
+	rgba2nv12 = openCl->compile(kernel_rgba2nv12_cl);
+	f2nv12 = openCl->compile(kernel_f2nv12_cl);
 }
 
 void Resources::raw2quad(const RawImage& img, std::shared_ptr<CLImage>* channels) {
@@ -47,4 +51,31 @@ void Resources::rgba2blobCenter(const std::shared_ptr<CLImage>* channels, std::s
 	cl::Event e3 = openCl->run(satHorizontal, cl::EnqueueArgs(e2, cl::NDRange(fh)), gradDot->image, gradDotHor->image);
 	cl::Event e4 = openCl->run(satVertical, cl::EnqueueArgs(e3, cl::NDRange(fw)), gradDotHor->image, gradDotSat->image);
 	openCl->await(satBlobCenter, cl::EnqueueArgs(e4, field), gradDotSat->image, blobCenter->image, p.circleRadius());
+}
+
+std::shared_ptr<CLImage> Resources::quad2rgba(std::shared_ptr<CLImage>* channels) {
+	std::shared_ptr<CLImage> rgba = openCl->acquire(&PixelFormat::RGBA8, channels[0]->width, channels[0]->height, channels[0]->name);
+	openCl->await(quad2rgbaKernel, cl::EnqueueArgs(cl::NDRange(channels[0]->width, channels[0]->height)), channels[0]->image, channels[1]->image, channels[2]->image, channels[3]->image, rgba->image);
+	return rgba;
+}
+
+std::shared_ptr<RawImage> Resources::streamQuad(std::shared_ptr<CLImage>* channels) {
+	std::shared_ptr<RawImage> nv12 = openCl->acquireNV12(channels[0]->width, channels[0]->height);
+	openCl->await(quad2nv12, cl::EnqueueArgs(cl::NDRange(channels[0]->width, channels[0]->height)), channels[0]->image, channels[1]->image, channels[2]->image, channels[3]->image, nv12->buffer);
+	return nv12;
+}
+
+std::shared_ptr<RawImage> Resources::streamImage(CLImage& img) {
+	cl::Kernel kernel;
+	if(img.format == &PixelFormat::RGBA8) {
+		kernel = rgba2nv12;
+	} else if(img.format == &PixelFormat::F32) {
+		kernel = f2nv12;
+	} else {
+		WARN("Unimplemented pixel format submitted for streaming.");
+		return nullptr;
+	}
+	std::shared_ptr<RawImage> nv12 = openCl->acquireNV12(img.width, img.height);
+	openCl->await(kernel, cl::EnqueueArgs(cl::NDRange(img.width, img.height)), img.image, nv12->buffer);
+	return nv12;
 }

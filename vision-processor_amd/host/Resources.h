@@ -63,7 +63,12 @@ public:
 	std::shared_ptr<OpenCL> openCl;
 
 	cl::Kernel raw2quadKernel, resampling, gradientDot, satHorizontal, satVertical, satBlobCenter;
+	cl::Kernel quad2rgbaKernel, quad2nv12, rgba2nv12, f2nv12; // Resources.cpp:127-130
 
 	void raw2quad(const RawImage& img, std::shared_ptr<CLImage>* channels); // Resources.cpp:138-143
 	void rgba2blobCenter(const std::shared_ptr<CLImage>* channels, std::shared_ptr<CLImage>& flat, std::shared_ptr<CLImage>& gradDot, std::shared_ptr<CLImage>& blobCenter); // :151-164
+	std::shared_ptr<CLImage> quad2rgba(std::shared_ptr<CLImage>* channels); // :145-149
+	// :166-186 -- the reference hands the NV12 frame to rtpStreamer->sendFrame (RTP/libav: out of scope); here the frame is returned
+	std::shared_ptr<RawImage> streamQuad(std::shared_ptr<CLImage>* channels);
+	std::shared_ptr<RawImage> streamImage(CLImage& img);
 };

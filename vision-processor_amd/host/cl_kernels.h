@@ -10,3 +10,7 @@ static const char* const kernel_satVertical_cl = "vp:sat_vertical";
 static const char* const kernel_satBlobCenter_cl = "vp:circle";
 static const char* const kernel_blobList_cl = "vp:blobList";
 static const char* const kernel_blobScore_cl = "vp:blobScore";
+static const char* const kernel_quad2rgba_cl = "vp:quad2rgba";
+static const char* const kernel_quad2nv12_cl = "vp:quad2nv12";
+static const char* const kernel_rgba2nv12_cl = "vp:rgb2nv12";
+static const char* const kernel_f2nv12_cl = "vp:f2nv12";

@@ -71,6 +71,7 @@ int main(int argc, char* argv[]) {
 		p.setGeometry(field, &calib, 1);
 	}
 	FILE* dump = argc > ai ? fopen(argv[ai], "wb") : nullptr;
+	FILE* debugDump = getenv("VP_DEBUG_DUMP") ? fopen(getenv("VP_DEBUG_DUMP"), "wb") : nullptr; // debugImages (main.cpp:291)
 
 	CLArray matchArray((int)sizeof(CLMatch) * r.maxBlobs); // main.cpp:257-258
 	CLArray counter((int)sizeof(int) * 3);
@@ -85,6 +86,25 @@ int main(int argc, char* argv[]) {
 		if(!p.geometryVersion) continue; // main.cpp:277
 		std::shared_ptr<CLImage> flat, gradDot, blobCenter;
 		r.rgba2blobCenter(channels, flat, gradDot, blobCenter);
+		if(debugDump && frameId == 1) { // main.cpp:291,377-403: the debug / stream views of the first frame
+			auto put = [&](const void* p, size_t bytes) {
+				const uint64_t n = bytes;
+				fwrite(&n, sizeof(n), 1, debugDump);
+				fwrite(p, 1, bytes, debugDump);
+			};
+			std::shared_ptr<CLImage> rgba = r.quad2rgba(channels);
+			{
+				CLImageMap<uint8_t> m = rgba->read<uint8_t>();
+				put(*m, rgba->bytes());
+			}
+			const size_t quadNv12 = vp_nv12_bytes(img->width, img->height), flatNv12 = vp_nv12_bytes(flat->width, flat->height);
+			for(const std::shared_ptr<RawImage>& nv : {r.streamQuad(channels), r.streamImage(*flat), r.streamImage(*blobCenter)}) {
+				CLMap<uint8_t> m = nv->read<uint8_t>();
+				put(*m, nv->width == img->width && nv->height == img->height ? quadNv12 : flatNv12);
+			}
+			fclose(debugDump);
+			debugDump = nullptr;
+		}
 		{
 			CLMap<int> counterMap = counter.write<int>(); // main.cpp:283-288
 			counterMap[0] = counterMap[1] = counterMap[2] = 0;

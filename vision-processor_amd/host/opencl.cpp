@@ -30,7 +30,11 @@ cl::Kernel OpenCL::compile(const char* code, const std::string& options) { // op
 	cl::Kernel k;
 	const std::string src(code ? code : "");
 	auto has = [&](const char* s) { return src.find(s) != std::string::npos; };
-	if(has("raw2quad")) k.id = cl::KernelId::raw2quad;
+	if(has("quad2rgba")) k.id = cl::KernelId::quad2rgba; // debug / stream colour kernels (Resources.cpp:127-130)
+	else if(has("quad2nv12")) k.id = cl::KernelId::quad2nv12;
+	else if(has("rgb2nv12")) k.id = cl::KernelId::rgb2nv12;
+	else if(has("f2nv12")) k.id = cl::KernelId::f2nv12;
+	else if(has("raw2quad")) k.id = cl::KernelId::raw2quad;
 	else if(has("resampling")) k.id = cl::KernelId::resampling;
 	else if(has("gradient_dotproduct")) k.id = cl::KernelId::gradientDot;
 	else if(has("sat_horizontal")) k.id = cl::KernelId::satHorizontal;
@@ -134,6 +138,22 @@ void OpenCL::dispatch(const cl::Kernel& k, const cl::EnqueueArgs& e, const std::
 	case cl::KernelId::blobCenter:
 		need(4);
 		VP_OR_FATAL(vp_circularize(ctx, 0, (const float*)a[0].p, a[0].w, a[0].h, 1, a[2].i, a[3].i, (float*)a[1].p));
+		break;
+	case cl::KernelId::quad2rgba: // Resources.cpp:147 -- (4 x U8 image, RGBA8 image) over NDRange(qw, qh)
+		need(5);
+		VP_OR_FATAL(vp_quad2rgba4(ctx, 0, (const uint8_t*)a[0].p, (const uint8_t*)a[1].p, (const uint8_t*)a[2].p, (const uint8_t*)a[3].p, k.layout, a[0].w, a[0].h, samplerMode, (uint8_t*)a[4].p));
+		break;
+	case cl::KernelId::quad2nv12: // Resources.cpp:168 -- (4 x U8 image, NV12 buffer)
+		need(5);
+		VP_OR_FATAL(vp_quad2nv124(ctx, 0, (const uint8_t*)a[0].p, (const uint8_t*)a[1].p, (const uint8_t*)a[2].p, (const uint8_t*)a[3].p, k.layout, a[0].w, a[0].h, samplerMode, (uint8_t*)a[4].p));
+		break;
+	case cl::KernelId::rgb2nv12: // Resources.cpp:184 -- (RGBA8 image, NV12 buffer)
+		need(2);
+		VP_OR_FATAL(vp_rgba2nv12(ctx, 0, (const uint8_t*)a[0].p, a[0].w, a[0].h, 1, (uint8_t*)a[1].p));
+		break;
+	case cl::KernelId::f2nv12: // Resources.cpp:184 -- (F32 image, NV12 buffer)
+		need(2);
+		VP_OR_FATAL(vp_f2nv12(ctx, 0, (const float*)a[0].p, a[0].w, a[0].h, 1, (uint8_t*)a[1].p));
 		break;
 	default:
 		FATAL("Enqueue kernel error: kernel not on the hot path");

@@ -34,7 +34,7 @@ typedef VpCameraModel CLCameraModel; // Perspective.h:22-29
 
 // ---- the sliver of the cl:: namespace the call sites use ------------------------------------------------------------------
 namespace cl {
-enum class KernelId { none, raw2quad, resampling, gradientDot, satHorizontal, satVertical, satBlobCenter, blobList, blobScore, blobCenter };
+enum class KernelId { none, raw2quad, resampling, gradientDot, satHorizontal, satVertical, satBlobCenter, blobList, blobScore, blobCenter, quad2rgba, quad2nv12, rgb2nv12, f2nv12 };
 struct Kernel {
 	KernelId id = KernelId::none;
 	int layout = VP_LAYOUT_RGGB; // from the -DRGGB / -DGRBG / -DBGR compile option (opencl.cpp:29-31)
