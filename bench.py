@@ -96,12 +96,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no fallback"
+    # VP_BENCH_REHEARSE=1 (tools only): every rank on cuda:0 with the gloo backend, to rehearse the N > 1 code path on a one-GPU box
+    rehearse = os.environ.get("VP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     vp = load()
     capi = vp.load_capi()
@@ -119,21 +126,34 @@ def main():
     sat = torch.empty((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
     # one fixed-size detection record per frame: [counter 3 x i32 | pad 4 | matches mm x 22 | idx mm x u32]
     rec_bytes = feeds.record_bytes(mm)
-    record = torch.zeros((B, rec_bytes), dtype=torch.uint8, device="cuda")
+    record = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]  # double-buffered: the gather of step k overlaps step k+1
     # vp_frame wants separate dense arrays; the record tensor is filled by three strided device copies per step
     matches = torch.zeros((B, 22 * mm), dtype=torch.uint8, device="cuda")
     idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
     counter = torch.zeros((B, 3), dtype=torch.int32, device="cuda")
-    gathered = torch.empty((world, B, rec_bytes), dtype=torch.uint8, device="cuda") if world > 1 else None
+    gathered = [torch.empty((world, B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    step_no = [0]
 
     def step():
         ctx.frame(params, d_raw, B, flat, sat, matches, counter, idx=idx)
         if world > 1:
-            feeds.pack_records(counter, matches, idx, record)
-            feeds.gather_records(record, gathered, dist)
+            s = step_no[0] & 1
+            step_no[0] += 1
+            if pending[s] is not None:
+                pending[s].wait()  # the gather issued two steps ago has released record[s] / gathered[s]
+            feeds.pack_records(counter, matches, idx, record[s])
+            pending[s] = feeds.gather_records(record[s], gathered[s], dist, async_op=True)
+
+    def drain():
+        for s in range(2):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     ctx.events_clear()
     ctx.events_enable(True)
@@ -143,6 +163,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()  # every step's gather has completed inside the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

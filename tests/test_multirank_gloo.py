@@ -64,6 +64,21 @@ def _worker(rank, world, port, batch, out_dir):
     for r in range(world):
         c, m, i = _detections(r, batch, cfg, mm)
         ok &= np.array_equal(gc[r].numpy(), c) and np.array_equal(gm[r].numpy(), m) and np.array_equal(gi[r].numpy(), i)
+    # the overlapped form bench.py uses: double-buffered records, async gathers, wait before a buffer is reused
+    recs = [torch.zeros_like(record) for _ in range(2)]
+    gath = [torch.zeros_like(gathered) for _ in range(2)]
+    pending = [None, None]
+    for k in range(5):
+        s = k & 1
+        if pending[s] is not None:
+            pending[s].wait()
+            ok &= int(gath[s][:, 0, 0].sum()) == sum(((k - 2) + r) % 251 for r in range(world))
+        recs[s].copy_(record)
+        recs[s][0, 0] = (k + rank) % 251  # a per-step, per-rank mark
+        pending[s] = f.gather_records(recs[s], gath[s], dist, async_op=True)
+    for s in range(2):
+        pending[s].wait()
+    ok &= torch.equal(gath[0][:, 1:], gathered[:, 1:]) and torch.equal(gath[1][:, 1:], gathered[:, 1:])
     # elapsed-time reduction used by bench.py: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -44,8 +44,10 @@ def unpack_records(gathered: torch.Tensor, max_matches: int):
     return counter, matches, idx
 
 
-def gather_records(record: torch.Tensor, gathered: torch.Tensor, dist) -> torch.Tensor:
-    """All-gather the per-rank record block: one collective per step, equal counts on every rank."""
+def gather_records(record: torch.Tensor, gathered: torch.Tensor, dist, async_op: bool = False):
+    """All-gather the per-rank record block: one collective per step, equal counts on every rank.
+    async_op=True returns the work handle: the collective then runs beside the next step's kernels (RCCL: its own stream);
+    the caller waits on the handle before it reuses `record` / reads `gathered`."""
     # flattened views: (world * B, bytes) <- (B, bytes); the gloo backend insists on the concatenated shape, RCCL accepts it too
-    dist.all_gather_into_tensor(gathered.view(-1, gathered.shape[-1]), record)
-    return gathered
+    work = dist.all_gather_into_tensor(gathered.view(-1, gathered.shape[-1]), record, async_op=async_op)
+    return work if async_op else gathered
