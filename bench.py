@@ -74,8 +74,20 @@ def cpu_baseline(cfg, seconds):
         one(n)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames of {cfg.name} through oracle/vp_oracle.c vpo_frame (fp32 sequential SAT, rows sharded over {cores} pthreads), {dt:.1f} s"}
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{n} frames of {cfg.name} through oracle/vp_oracle.c vpo_frame (fp32 sequential SAT, rows sharded over {cores} pthreads), {dt:.1f} s"}
+    # For information: the reference's own kernel/*.cl compiled for x86 (oracle/_ref, prebuilt in the build container and carried
+    # along), run the way a CPU OpenCL device would run one work-item at a time -- sequential NDRange, one core, two frames.
+    if O.Ref.available():
+        ref = O.Ref()
+        t0 = time.perf_counter()
+        for i in range(2):
+            planes = ref.raw2quad(raws[i], cfg.layout, cfg.qw, cfg.qh)
+            flat = ref.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode, cfg.fw, cfg.fh)
+            ref.chain_from_flat(flat, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, cfg.max_matches)
+        out["reference_kernels"] = {"value": round(2 / (time.perf_counter() - t0), 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                    "sample": "2 frames through the reference's .cl kernels compiled for x86 (oracle/_ref), sequential NDRange loops"}
+    return out
 
 
 def main():
