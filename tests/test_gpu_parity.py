@@ -353,6 +353,33 @@ def test_full_size_properties(gpu, port):
     assert 60 <= len(strong) <= 200
 
 
+def test_cfg5_high_res_frame_vs_oracle(gpu):
+    """BASELINE.json configs[4] (4096x3072, o = 3, r = 9, R = 8): one frame end to end against the CPU oracle, LDS-tiled and
+    global-recursive SAT variants (the o = 3 instantiation of the tiled kernel aliases its sub-segment totals over the raw tile)."""
+    capi, ctx, torch = gpu
+    cfg = cfgs.CFG5
+    assert (cfg.grad_offset, cfg.circle_radius, cfg.list_radius) == (3, 9, 8)
+    raw = cfg.synth(11)
+    mm = cfg.max_matches
+    d_raw = dev(torch, raw[None])
+    model_o = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    big = O.Port(threads=8)
+    m, idx, cnt = big.frame(raw, cfg.layout, cfg.qw, cfg.qh, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                            cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+    assert 50 < len(m) <= mm
+    sats = []
+    for name, variant in VARIANTS:
+        p = capi.frame_params(cfg, sat_variant=variant, order=capi.ORDER_RASTER)
+        d = dict(flat=torch.zeros((1, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((1, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+                 matches=torch.zeros((1, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((1, mm), dtype=torch.int32, device="cuda"),
+                 counter=torch.zeros((1, 3), dtype=torch.int32, device="cuda"))
+        ctx.frame(p, d_raw, 1, **d)
+        ctx.sync()
+        assert_list_equal(capi, (host(d["matches"][0]), host(d["idx"][0]).view(np.uint32), host(d["counter"][0])), np.frombuffer(m.tobytes(), np.uint8), idx, cnt, mm)
+        sats.append(host(d["sat"][0]))
+    assert all(np.array_equal(sats[0], s) for s in sats[1:])
+
+
 @pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.T_RGGB], ids=lambda c: c.name)
 @pytest.mark.parametrize("o", [1, 2, 3, 4])
 def test_halo_strips_path(gpu, port, cfg, o):
