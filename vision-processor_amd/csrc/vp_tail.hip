@@ -306,17 +306,27 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 	// [x0-1-r, x0+FT_W+1], v likewise (its origin coincides with the region's); wrapping int32 arithmetic, exact.
 	const int BXW = FT_W + r + 3, BXH = FT_H + r + 3;
 	int32_t* bx = reinterpret_cast<int32_t*>(region + RW * RH);
-	for(int e = tid; e < BXW * BXH; e += FT_NT) {
-		const int by = e / BXW, bxx = e - by * BXW;
+	// A wavefront that straddled two rows of the 72-wide image would touch a span of more than 64 dwords: 2-way bank conflicts on
+	// every tap (measured: SQ_LDS_BANK_CONFLICT = 54 % of the LDS cycles).  So: columns 0..63 with one row per wavefront, then the
+	// few remaining columns.
+	auto bx_entry = [&](int by, int bxx) {
 		const uint32_t* c = region + by * RW + bxx + XO;
-		bx[e] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
+		bx[by * BXW + bxx] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
+	};
+	for(int e = tid; e < 64 * BXH; e += FT_NT) bx_entry(e >> 6, e & 63);
+	{
+		const int extra = BXW - 64; // r + 3 columns
+		for(int e = tid; e < extra * BXH; e += FT_NT) {
+			const int by = e / extra;
+			bx_entry(by, 64 + (e - by * extra));
+		}
 	}
 	__syncthreads();
 	const float div = (float)(r * r), rcp = 1.0f / div;
 	constexpr int BW = FT_W + 2, BH = FT_H + 2;
 	float* bc = reinterpret_cast<float*>(region); // the blobCenter ring tile aliases the (now dead) SAT region
-	for(int e = tid; e < BW * BH; e += FT_NT) {
-		const int by = e / BW, bxx = e - by * BW;
+	auto bc_entry = [&](int by, int bxx) {
+		const int e = by * BW + bxx;
 		// clamped centre, in Bx coordinates (origin x0-1-r, y0-1-r)
 		const int cx = vp_clampi(x0 - 1 + bxx, 0, w - 1) - (x0 - 1 - r), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - 1 - r);
 		const int32_t* c = bx + cy * BXW + cx;
@@ -333,7 +343,9 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 			const float q0 = m * rcp;
 			bc[e] = __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
 		} else bc[e] = m / div;
-	}
+	};
+	for(int e = tid; e < 64 * BH; e += FT_NT) bc_entry(e >> 6, e & 63); // one row per wavefront (see above), then the two ring columns
+	for(int e = tid; e < 2 * BH; e += FT_NT) bc_entry(e >> 1, 64 + (e & 1));
 	__syncthreads();
 	for(int e = tid; e < FT_W * FT_H; e += FT_NT) {
 		const int ty = e / FT_W, tx = e - ty * FT_W;
