@@ -13,7 +13,7 @@ import numpy as np
 from .hostlib import VpCameraModel
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(HERE, "libvp_hip.so")
+HIP_SO = os.environ.get("VP_HIP_LIB") or os.path.join(HERE, "libvp_hip.so")  # VP_HIP_LIB: A/B builds side by side (tools only)
 
 VP_OK = 0
 SAT_TILED, SAT_TWOPASS = 0, 1

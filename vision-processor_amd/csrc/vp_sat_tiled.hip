@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 	int* Bv = Av + TW;
 	int* misc = Bv + TH; // [0] first ticket, [1] K, [2] Q, [3] next ticket, [4] wave slot
 	int* T16 = ALIAS ? reinterpret_cast<int*>(smem) : misc + 8; // [16][64] column totals of the 4-row sub-segments
+	int* Rc = (ALIAS ? misc + 8 : T16 + 16 * TW);               // [64] right column of the sub-segment-local SAT (for the row chain)
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int w = a.w, h = a.h;
@@ -547,8 +548,12 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX);
 		}
 
-		// ---- B: 4 pixels per lane; lane = 16 q + m: columns 4m..4m+3, rows 16 wv + 4 q + it ---------------------------
-		const int m = lane & 15, q = lane >> 4;
+		// ---- B: 4 pixels per lane; lane = 16 ql + m: columns 4m..4m+3, rows 16 wv + 4 q + it --------------------------
+		// q = bit-reversed ql: a ds_read_b128 is serviced in four 16-lane groups that each mix lanes of two adjacent 16-lane rows
+		// ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md, LDS); with the 72-dword pitch those two rows must lie a multiple of 8 tile
+		// rows apart (72 * 8 = 0 mod 64 banks) for the group to cover 64 distinct banks.  ql = 0,1,2,3 -> row blocks 0, 8, 4, 12:
+		// all five tap reads are conflict-free (with q = ql every one of them was 2-way conflicted).
+		const int m = lane & 15, ql = lane >> 4, q = ((ql & 1) << 1) | (ql >> 1);
 		int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
 #pragma unroll 1
 		for(int it = 0; it < (abl_comp ? 0 : 4); it++) {
@@ -578,6 +583,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			run2 += g2 + ex;
 			run3 += g3 + ex;
 			*reinterpret_cast<int4*>(S + r * TW + 4 * m) = make_int4(run0, run1, run2, run3);
+			if(m == 15) Rc[r] = run3; // S[r][63], compact: the row chain reads it without the 32-way bank conflict of a column read
 		}
 		const unsigned long long tsb1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		if(ALIAS) lds_barrier(); // every wave is done with raw before T16 overwrites it
@@ -601,8 +607,10 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pc);
 			Av[lane] = carry;
 		} else if(wv == 1) { // row chain: B(y), then the corner chain's aggregate Q = B(TH-1)
-			int pr = S[lane * TW + TW - 1]; // right column of the local SAT
-			for(int sg = 0; sg < (lane >> 2); sg++) pr += T16[sg * TW + TW - 1];
+			// right column of the local SAT = sub-segment-local value + totals of the sub-segments above: an exclusive prefix over
+			// sub-segments, done as one wave scan (4 lanes share a sub-segment) instead of a dependent loop of up to 15 LDS reads
+			const int t = T16[(lane >> 2) * TW + TW - 1];
+			const int pr = Rc[lane] + scan_incl_dpp((lane & 3) == 0 ? t : 0) - t;
 			u64* g = a.H + tile * TH + lane;
 			int carry = 0;
 			if(!abl_gran && tj > 0 && !early_resolve(pre0, pre1, tj, a, carry)) {
@@ -783,7 +791,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	const bool fast = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
 			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0) && !(a.debug & 16);
 	if(fast) {
-		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8 + (o <= 2 ? 16 * TW : 0));
+		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8 + (o <= 2 ? 16 * TW : 0) + TH);
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
 #define VP_FAST(OO) \
 		do { \
