@@ -359,14 +359,14 @@ __global__ __launch_bounds__(256) void k_resample_map(float2* __restrict__ map, 
 
 // FPT frames of the batch per thread: the coordinate and everything derived from it (tap offsets, selectors, weights) are
 // computed once and reused, so the 8 B/px map is read once per FPT frames instead of once per frame.
-constexpr int RESAMPLE_FPT = 8;
+constexpr int RESAMPLE_FPT = 16; // measured on the 128-frame workload: 8 -> 853 us, 16 -> 800 us, 32 -> 867 us (LDS stage 16 / 16 / 32 KB per workgroup)
 
 // The 256 pixels of a workgroup (64 x 4 of flat) need only about a kilobyte of distinct sensor bytes per frame, yet every
 // lane fetching its own four 8-byte windows keeps the texture addresser busy 85 % of the kernel (~36 TA cycles per unaligned
 // wave load).  So the workgroup finds the bounding box of its windows once (frame independent), then per frame stages that box
 // in LDS with ONE coalesced dword load per thread (double buffered, one barrier per frame) and reads the windows from LDS.
 // Boxes too large for the stage (exotic geometries) take the direct path; results are identical either way.
-constexpr int STAGE_DW = 512; // dwords per frame box in the stage
+constexpr int STAGE_DW = 256; // dwords per frame box in the stage
 
 // packed-u16 min / max (v_pk_min_u16 / v_pk_max_u16) and their wave reductions in DPP (row_shr 1,2,4,8, row_bcast 15 and 31; the
 // result is read from lane 63)
