@@ -112,14 +112,17 @@ static inline int vp_launch_ok(const char* what) {
 
 static inline unsigned vp_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-// Halo strips (include/vp_hip.h): per frame two arrays [tilesX][h][offset] of RGBA8 pixels; entry (b, y, k) of the first holds
-// flat[y][64 b - offset + k] (the pixels left of boundary b), of the second flat[y][64 b + k] (right of it).  b = 0 is unused.
+// Halo strips (include/vp_hip.h): per frame one EDGE RECORD of 2*offset RGBA8 pixels per (64-pixel tile column j, row y):
+// [first `offset` pixels of the tile row | last `offset` pixels], i.e. flat[y][64 j + k] and flat[y][64 j + 64 - offset + k].
+// The wavefront that produces a 64-pixel tile row writes its record with ONE masked store.  A SAT tile takes its left halo
+// from the upper half of its left neighbour's record and its right halo from the lower half of its right neighbour's.
 struct VpStrips {
 	uint32_t* base;       // nullptr: not in use
 	int tiles_x, h, o;
 	size_t frame_words;   // uint32 per frame = 2 * tiles_x * h * o
-	__host__ __device__ size_t left(int b, int y, int k) const { return ((size_t)b * h + y) * o + k; }
-	__host__ __device__ size_t right(int b, int y, int k) const { return ((size_t)(tiles_x + b) * h + y) * o + k; }
+	__host__ __device__ size_t rec(int j, int y, int e) const { return ((size_t)j * h + y) * (2 * o) + e; }
+	__host__ __device__ size_t left(int b, int y, int k) const { return rec(b - 1, y, o + k); } // flat[y][64 b - o + k], b >= 1
+	__host__ __device__ size_t right(int b, int y, int k) const { return rec(b, y, k); }        // flat[y][64 b + k]
 };
 static inline bool vp_strips_supported(int w, int offset) { return w > 0 && (w % 64) == 0 && offset >= 1 && offset <= 4; }
 static inline VpStrips vp_make_strips(uint32_t* base, int w, int h, int offset) {

@@ -96,10 +96,10 @@ extern "C" int vp_raw2quad4(VpContext* ctx, int stream, const uint8_t* raw, int 
 // While writing a flat pixel, also drop it into the halo strips if it sits within `o` pixels of a 64-pixel tile boundary.
 __device__ __forceinline__ void emit_strip(const VpStrips& st, int frame, int gx, int gy, uint32_t px4) {
 	if(!st.base) return;
-	const int xm = gx & 63, b = gx >> 6;
+	const int xm = gx & 63, j = gx >> 6;
 	uint32_t* f = st.base + (size_t)frame * st.frame_words;
-	if(xm >= 64 - st.o && b + 1 < st.tiles_x) f[st.left(b + 1, gy, xm - (64 - st.o))] = px4;
-	if(xm < st.o && b > 0) f[st.right(b, gy, xm)] = px4;
+	if(xm < st.o) f[st.rec(j, gy, xm)] = px4;
+	else if(xm >= 64 - st.o) f[st.rec(j, gy, xm - 64 + 2 * st.o)] = px4;
 }
 
 struct ResampleArgs {
@@ -320,14 +320,13 @@ __global__ __launch_bounds__(256) void k_resample(const uint8_t* __restrict__ sr
 __global__ __launch_bounds__(256) void k_halo_strips(const uint32_t* __restrict__ flat, const VpStrips st, int w) {
 	// one thread per (boundary, row, side, k)
 	const int per_row = 2 * st.o;
-	const size_t total = (size_t)(st.tiles_x - 1) * st.h * per_row;
+	const size_t total = (size_t)st.tiles_x * st.h * per_row;
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if(i >= total) return;
-	const int e = (int)(i % per_row), y = (int)((i / per_row) % st.h), b = 1 + (int)(i / ((size_t)per_row * st.h));
+	const int e = (int)(i % per_row), y = (int)((i / per_row) % st.h), j = (int)(i / ((size_t)per_row * st.h));
 	const uint32_t* f = flat + (size_t)blockIdx.y * w * st.h;
 	uint32_t* out = st.base + (size_t)blockIdx.y * st.frame_words;
-	if(e < st.o) out[st.left(b, y, e)] = f[(size_t)y * w + 64 * b - st.o + e];
-	else out[st.right(b, y, e - st.o)] = f[(size_t)y * w + 64 * b + (e - st.o)];
+	out[st.rec(j, y, e)] = f[(size_t)y * w + 64 * j + (e < st.o ? e : 64 - 2 * st.o + e)];
 }
 
 extern "C" size_t vp_halo_strip_bytes(int w, int h, int offset) {
@@ -341,7 +340,7 @@ extern "C" int vp_halo_strips(VpContext* ctx, int stream, const uint8_t* flat, i
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, "halo strips");
 	const VpStrips st = vp_make_strips(strips, w, h, offset);
-	const size_t total = (size_t)(st.tiles_x - 1) * h * 2 * offset;
+	const size_t total = (size_t)st.tiles_x * h * 2 * offset;
 	if(total == 0) return VP_OK;
 	k_halo_strips<<<dim3((unsigned)((total + 255) / 256), batch), 256, 0, ctx->streams[stream]>>>(reinterpret_cast<const uint32_t*>(flat), st, w);
 	return vp_launch_ok("halo strips");
@@ -429,10 +428,9 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			const uint32_t voff_out = 4u * (uint32_t)(min(gy, fh - 1) * fw + min(gx, fw - 1));
 			// halo-strip destinations of this pixel (emit_strip(), hoisted out of the frame loop)
 			const int xm = gx & 63, tb = gx >> 6;
-			const bool sl = valid && strips.base && xm >= 64 - strips.o && tb + 1 < strips.tiles_x, sr = valid && strips.base && xm < strips.o && tb > 0;
-			const uint32_t so = (uint32_t)strips.o, sh = (uint32_t)strips.h; // VpStrips::left/right in 32-bit arithmetic (frame_words * 4 < 2 GiB)
-			const uint32_t voff_sl = sl ? 4u * (((uint32_t)(tb + 1) * sh + (uint32_t)gy) * so + (uint32_t)(xm - 64) + so) : 0u;
-			const uint32_t voff_sr = sr ? 4u * (((uint32_t)(strips.tiles_x + tb) * sh + (uint32_t)gy) * so + (uint32_t)xm) : 0u;
+			const uint32_t so = (uint32_t)strips.o, sh = (uint32_t)strips.h; // VpStrips::rec in 32-bit arithmetic (frame_words * 4 < 2 GiB)
+			const bool se = valid && strips.base && (xm < strips.o || xm >= 64 - strips.o); // this pixel belongs to its tile row's edge record
+			const uint32_t voff_se = se ? 4u * ((((uint32_t)tb * sh + (uint32_t)gy) * 2u * so) + (uint32_t)(xm < strips.o ? xm : xm - 64 + 2 * strips.o)) : 0u;
 			const int wcol = g.d0 - cmin;
 			const int ie0 = (g.re0 - rmin) * wdw + wcol, ie1 = (g.re1 - rmin) * wdw + wcol, io0 = (g.ro0 - rmin) * wdw + wcol, io1 = (g.ro1 - rmin) * wdw + wcol;
 			// which dwords of the box this thread fetches, NP pieces of 256 (lanes past the box re-fetch its first dword: harmless)
@@ -473,8 +471,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
 					// (lanes past the right/bottom edge hold the clamped pixel's own value: the duplicate store is harmless)
 					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
-					if(sl) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sl, (uint32_t)j * fb_strip, 0);
-					if(sr) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_sr, (uint32_t)j * fb_strip, 0);
+					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
 				}
 			};
 			if(ndw <= 256) run(std::integral_constant<int, 1>());
