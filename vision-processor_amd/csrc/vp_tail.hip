@@ -313,8 +313,26 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 		const uint32_t* c = region + by * RW + bxx + XO;
 		bx[by * BXW + bxx] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
 	};
-	for(int e = tid; e < 64 * BXH; e += FT_NT) bx_entry(e >> 6, e & 63);
-	{
+	// Odd compile-time radius, interior tile: two horizontally adjacent entries per thread through 8-byte LDS accesses (ds_read_b64 /
+	// ds_write_b64 move 256 B per clock, the 4-byte forms 128 B).  With r odd every tap of an even-column pair is 8-byte aligned:
+	// RW, BXW, BW and XO are even and the blobCenter taps sit at odd offsets (+1, -r) from an odd column (bxx + r).
+	constexpr bool PAIRS = RT > 0 && (RT & 1) == 1;
+	const bool pairs = PAIRS && interior; // workgroup-uniform
+	if(pairs) {
+		auto bx_pair = [&](int by, int bxx) {
+			const uint32_t* c = region + by * RW + bxx + XO;
+			const uint2 t11 = *reinterpret_cast<const uint2*>(c + (r - 1) * RW + (r - 1)), t10 = *reinterpret_cast<const uint2*>(c + (r - 1));
+			const uint2 t01 = *reinterpret_cast<const uint2*>(c + (r - 1) * RW), t00 = *reinterpret_cast<const uint2*>(c);
+			*reinterpret_cast<int2*>(bx + by * BXW + bxx) = make_int2((int32_t)(t11.x - t10.x - t01.x + t00.x), (int32_t)(t11.y - t10.y - t01.y + t00.y));
+		};
+		for(int e = tid; e < 32 * BXH; e += FT_NT) bx_pair(e >> 5, 2 * (e & 31)); // one row per 32-lane half (the bank-conflict group of b64)
+		const int xp = (BXW - 64) / 2;
+		for(int e = tid; e < xp * BXH; e += FT_NT) {
+			const int by = e / xp;
+			bx_pair(by, 64 + 2 * (e - by * xp));
+		}
+	} else {
+		for(int e = tid; e < 64 * BXH; e += FT_NT) bx_entry(e >> 6, e & 63);
 		const int extra = BXW - 64; // r + 3 columns
 		for(int e = tid; e < extra * BXH; e += FT_NT) {
 			const int by = e / extra;
@@ -344,8 +362,35 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 			bc[e] = __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
 		} else bc[e] = m / div;
 	};
-	for(int e = tid; e < 64 * BH; e += FT_NT) bc_entry(e >> 6, e & 63); // one row per wavefront (see above), then the two ring columns
-	for(int e = tid; e < 2 * BH; e += FT_NT) bc_entry(e >> 1, 64 + (e & 1));
+	if(pairs) { // interior: no clamping, cx = bxx + r, cy = by + r
+		auto quot = [&](float m) {
+			const float q0 = m * rcp;
+			return __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0); // PAIRS implies 3 <= RT <= 9: see bc_entry
+		};
+		auto bc_pair = [&](int by, int bxx) {
+			const int32_t* c = bx + (by + r) * BXW + bxx + r;
+			const int2 ppi = *reinterpret_cast<const int2*>(c + BXW + 1), nni = *reinterpret_cast<const int2*>(c - r * BXW - r);
+			const int2 pni = *reinterpret_cast<const int2*>(c - r * BXW + 1), npi = *reinterpret_cast<const int2*>(c + BXW - r);
+			float2 o;
+			{
+				const float pp = (float)ppi.x, nn = (float)nni.x, pn = (float)(-pni.x), np = (float)(-npi.x);
+				const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
+				o.x = quot(b < a ? b : a);
+			}
+			{
+				const float pp = (float)ppi.y, nn = (float)nni.y, pn = (float)(-pni.y), np = (float)(-npi.y);
+				const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
+				o.y = quot(b < a ? b : a);
+			}
+			*reinterpret_cast<float2*>(bc + by * BW + bxx) = o;
+		};
+		static_assert(!PAIRS || (RT >= 3 && RT <= 10), "the fma quotient is verified for r = 3 .. 10 only");
+		for(int e = tid; e < 32 * BH; e += FT_NT) bc_pair(e >> 5, 2 * (e & 31));
+		for(int e = tid; e < BH; e += FT_NT) bc_pair(e, 64); // the ring columns 64, 65
+	} else {
+		for(int e = tid; e < 64 * BH; e += FT_NT) bc_entry(e >> 6, e & 63); // one row per wavefront (see above), then the two ring columns
+		for(int e = tid; e < 2 * BH; e += FT_NT) bc_entry(e >> 1, 64 + (e & 1));
+	}
 	__syncthreads();
 	for(int e = tid; e < FT_W * FT_H; e += FT_NT) {
 		const int ty = e / FT_W, tx = e - ty * FT_W;
