@@ -261,16 +261,18 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 	const int32_t* sat = sat_all + z * n;
 	const int x0 = (int)(trem % tiles_x) * FT_W, y0 = (int)(trem / tiles_x) * FT_H;
 	const int tid = threadIdx.x;
-	const bool interior = RT > 0 && x0 - HA >= 0 && x0 + FT_W + HA <= w && y0 - halo >= 0 && y0 + FT_H + halo <= h && (w & 3) == 0 &&
-			(reinterpret_cast<uintptr_t>(sat_all) & 15) == 0;
-	if(interior) { // workgroup-uniform
+	const bool vec_ok = RT > 0 && (w & 3) == 0 && w >= 4 && (reinterpret_cast<uintptr_t>(sat_all) & 15) == 0;
+	const bool interior = vec_ok && x0 - HA >= 0 && x0 + FT_W + HA <= w && y0 - halo >= 0 && y0 + FT_H + halo <= h;
+	if(vec_ok) { // workgroup-uniform.  Border tiles too: rows clamp by index; a 4-pixel group is either wholly inside the image or wholly
+	             // outside it (w, x0 and HA are multiples of 4), and an outside group is the edge column replicated (clamp-to-edge)
 		constexpr int RW4 = RT > 0 ? (FT_W + 2 * ((RT + 1 + 3) & ~3)) / 4 : 1, RHc = RT > 0 ? FT_H + 2 * (RT + 1) : 1, NV = (RW4 * RHc + FT_NT - 1) / FT_NT;
-		const int32_t* tb = sat + (size_t)(y0 - halo) * w + (x0 - HA); // uniform base; 32-bit lane offsets below
 		int4 v4[NV];
 #pragma unroll
 		for(int k = 0; k < NV; k++) {
 			const int i = min(tid + FT_NT * k, RW4 * RHc - 1), row = i / RW4, c4 = i - row * RW4;
-			v4[k] = *reinterpret_cast<const int4*>(tb + (uint32_t)(row * w + 4 * c4));
+			const int gy = interior ? y0 - halo + row : vp_clampi(y0 - halo + row, 0, h - 1), gx = x0 - HA + 4 * c4;
+			const int4 v = *reinterpret_cast<const int4*>(sat + (size_t)gy * w + (interior ? gx : vp_clampi(gx, 0, w - 4)));
+			v4[k] = interior || (gx >= 0 && gx < w) ? v : (gx < 0 ? make_int4(v.x, v.x, v.x, v.x) : make_int4(v.w, v.w, v.w, v.w));
 		}
 #pragma unroll
 		for(int k = 0; k < NV; k++)
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 	// ds_write_b64 move 256 B per clock, the 4-byte forms 128 B).  With r odd every tap of an even-column pair is 8-byte aligned:
 	// RW, BXW, BW and XO are even and the blobCenter taps sit at odd offsets (+1, -r) from an odd column (bxx + r).
 	constexpr bool PAIRS = RT > 0 && (RT & 1) == 1;
-	const bool pairs = PAIRS && interior; // workgroup-uniform
-	if(pairs) {
+	const bool pairs = PAIRS && interior; // workgroup-uniform; blobCenter clamps its centre on border tiles, the box sums never clamp
+	if(PAIRS && vec_ok) {
 		auto bx_pair = [&](int by, int bxx) {
 			const uint32_t* c = region + by * RW + bxx + XO;
 			const uint2 t11 = *reinterpret_cast<const uint2*>(c + (r - 1) * RW + (r - 1)), t10 = *reinterpret_cast<const uint2*>(c + (r - 1));
