@@ -58,6 +58,13 @@ __device__ __forceinline__ void st_granule(u64* p, uint32_t epoch, uint32_t stat
 	__hip_atomic_store((gu64*)p, ((u64)((epoch << 2) | state) << 32) | (uint32_t)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// streaming (non-temporal) 16-byte load: the flat tile is read once by this kernel
+__device__ __forceinline__ uint4 nt_load_u4(const uint32_t* p) {
+	typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+	const v4u_ v = __builtin_nontemporal_load(reinterpret_cast<const v4u_*>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // inclusive wave-64 prefix sum in 6 DPP adds (row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31)
 __device__ __forceinline__ int scan_incl_dpp(int v) {
 	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 	uint32_t hv0 = 0, hv1 = 0, hv2 = 0;
 	const int c4 = tid & 15, r16 = tid >> 4;
 #define VP_PF_ROW(P) (min(r16 + 16 * (P), ROWS - 1))
-#define VP_PF_LOAD(P, X0, Y0) (*reinterpret_cast<const uint4*>(flat + (size_t)vp_clampi((Y0) - O + VP_PF_ROW(P), 0, h - 1) * w + (X0) + 4 * c4))
+#define VP_PF_LOAD(P, X0, Y0) nt_load_u4(flat + (size_t)vp_clampi((Y0) - O + VP_PF_ROW(P), 0, h - 1) * w + (X0) + 4 * c4)
 #define VP_HALO_E(J) (min(tid + 256 * (J), ROWS * 2 * O - 1))
 #define VP_HALO_GX(J, X0) ((VP_HALO_E(J) % (2 * O)) < O ? (X0) - O + (VP_HALO_E(J) % (2 * O)) : (X0) + TW + (VP_HALO_E(J) % (2 * O)) - O)
 	// halo element J of the tile at (X0, Y0): from the compact strips when they exist and the neighbour tile does (interior
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 				}
 				const int4 sv = *reinterpret_cast<const int4*>(S + r * TW + 4 * cg);
 				const int b = Bv[r];
-				if(gy < h && !abl_store) *reinterpret_cast<int4*>(out + (size_t)gy * w + gx) = make_int4(sv.x + add.x + b, sv.y + add.y + b, sv.z + add.z + b, sv.w + add.w + b);
+				if(gy < h && !abl_store) { typedef int v4i_ __attribute__((ext_vector_type(4))); const v4i_ o4 = {sv.x + add.x + b, sv.y + add.y + b, sv.z + add.z + b, sv.w + add.w + b}; __builtin_nontemporal_store(o4, reinterpret_cast<v4i_*>(out + (size_t)gy * w + gx)); }
 			}
 		}
 		if(stamp) {
