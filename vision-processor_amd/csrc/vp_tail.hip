@@ -271,7 +271,9 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 		for(int k = 0; k < NV; k++) {
 			const int i = min(tid + FT_NT * k, RW4 * RHc - 1), row = i / RW4, c4 = i - row * RW4;
 			const int gy = interior ? y0 - halo + row : vp_clampi(y0 - halo + row, 0, h - 1), gx = x0 - HA + 4 * c4;
-			const int4 v = *reinterpret_cast<const int4*>(sat + (size_t)gy * w + (interior ? gx : vp_clampi(gx, 0, w - 4)));
+			typedef int v4i_ __attribute__((ext_vector_type(4)));
+			const v4i_ vv = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sat + (size_t)gy * w + (interior ? gx : vp_clampi(gx, 0, w - 4))));
+			const int4 v = make_int4(vv.x, vv.y, vv.z, vv.w);
 			v4[k] = interior || (gx >= 0 && gx < w) ? v : (gx < 0 ? make_int4(v.x, v.x, v.x, v.x) : make_int4(v.w, v.w, v.w, v.w));
 		}
 #pragma unroll
