@@ -76,16 +76,21 @@ __device__ __forceinline__ int scan_incl_dpp(int v) {
 	return v;
 }
 
-// sum over channels of (xp - xn) * (yp - yn) on RGBA8 taps: bytes widened to 16-bit pairs (R,B) / (G,A), packed
-// subtraction, 2-way integer dot products.  Alpha is 255 on every tap, its difference is 0.  (gradientDot.cl:25-29)
+// sum over channels of (xp - xn) * (yp - yn) on RGBA8 taps (gradientDot.cl:25-29).  Alpha is 255 on every tap: its difference
+// is 0 and is left out.  The byte differences are formed by SDWA subtractions that read one byte of each operand and write
+// one 16-bit half of the result (v_sub_u16_sdwa ... src_sel:BYTE_n dst_sel:WORD_m): (R, B) packed in one register, G in
+// another, then two 2-way 16-bit dot products.  8 VALU instructions per pixel; the mask / shift / v_pk_sub_i16 form took 14
+// and this phase is what bounds the kernel (measured: ~60 % of the pass is VALU issue time).
 __device__ __forceinline__ int grad_dot_pk(uint32_t xp, uint32_t xn, uint32_t yp, uint32_t yn) {
-	const uint32_t m = 0x00FF00FFu;
-	const uint32_t gxl = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, xp & m) - __builtin_bit_cast(short2v, xn & m));
-	const uint32_t gxh = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, (xp >> 8) & m) - __builtin_bit_cast(short2v, (xn >> 8) & m));
-	const uint32_t gyl = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, yp & m) - __builtin_bit_cast(short2v, yn & m));
-	const uint32_t gyh = __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, (yp >> 8) & m) - __builtin_bit_cast(short2v, (yn >> 8) & m));
-	int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, gxl), __builtin_bit_cast(short2v, gyl), 0, false);
-	acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, gxh), __builtin_bit_cast(short2v, gyh), acc, false);
+	uint32_t gx_rb, gx_g, gy_rb, gy_g;
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(gx_rb) : "v"(xp), "v"(xn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(gx_rb) : "v"(xp), "v"(xn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(gx_g) : "v"(xp), "v"(xn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(gy_rb) : "v"(yp), "v"(yn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(gy_rb) : "v"(yp), "v"(yn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(gy_g) : "v"(yp), "v"(yn));
+	int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, gx_rb), __builtin_bit_cast(short2v, gy_rb), 0, false);
+	acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, gx_g), __builtin_bit_cast(short2v, gy_g), acc, false);
 	return acc;
 }
 
@@ -691,6 +696,284 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 #undef VP_COMMIT_HALO
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation of the fast path.  k_sat_fast is limited by the bytes it keeps in flight: 4 workgroups per CU (LDS 40.8 KB
+// and ~121 VGPRs each) x 20 KB of prefetch, and only between the prefetch and its use.  Here
+//   * the sub-segment-local SAT plane S (16 KB of LDS) lives in registers: phase E uses phase B's pixel-to-lane mapping, so the
+//     16 values a lane produced are the 16 values it completes and stores;
+//   * the prefetch addresses are 32-bit lane offsets against buffer descriptors with a scalar tile offset (no 64-bit VGPR
+//     arithmetic, no divisions in the loop: the register peak of k_sat_fast sat in exactly that code);
+// which brings a workgroup to 24.6 KB of LDS and <= WPC-dependent VGPR budget: WPC = 5 or 6 workgroups per CU.
+// Works for every O in 1..4 (nothing aliases the raw tile).  Same granule protocol, same tile order, same results.
+template<int O, int WPC>
+__global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
+	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
+	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
+	constexpr int NI = (ROWS + 15) / 16;             // interior: 16 lanes x 16 B per row, 16 rows per pass
+	constexpr int NHS = (ROWS * O + 255) / 256;      // halo dwords per thread and side
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	uint32_t* raw = reinterpret_cast<uint32_t*>(smem);
+	int* T16 = reinterpret_cast<int*>(raw + ROWS * PITCH); // [16][64] column totals of the 4-row sub-segments
+	int* T16P = T16 + 16 * TW;                             // [16][64] exclusive prefix of T16 over sub-segments (wave 3, during C/D)
+	int* Rc = T16P + 16 * TW;                              // [64] right column of the sub-segment-local SAT
+	int* Av = Rc + TH;
+	int* Bv = Av + TW;
+	int* misc = Bv + TH; // [0] first ticket, [1] K, [2] Q, [3] next ticket
+
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int w = a.w, h = a.h;
+	const int perFrame = a.tilesX * a.tilesY;
+	const int f = (int)(blockIdx.x % (unsigned)a.batch);
+	uint32_t* queue = a.ctrl + 16 + 16 * f;
+	const size_t frame = (size_t)f * w * h;
+	const bool loader = tid == 3 * 64;
+
+	uint32_t pending = 0;
+	if(loader) {
+		const uint32_t t0 = atomicAdd(queue, 1u);
+		pending = atomicAdd(queue, 1u);
+		misc[0] = (int)(t0 - a.ticket_base);
+	}
+	__syncthreads();
+	int rem = misc[0];
+	if(rem < 0 || rem >= perFrame) return;
+
+	// buffer descriptors of this frame (host guarantees w * h * 4 < 2^31): 32-bit lane offsets + a scalar tile offset
+	const uint32_t frame_bytes = (uint32_t)w * (uint32_t)h * 4u, row_bytes = (uint32_t)w * 4u;
+	const __amdgpu_buffer_rsrc_t rs_flat = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(in + frame), 0, (int)frame_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(sat + frame, 0, (int)frame_bytes, 0x00020000);
+	const bool use_strips = a.strips.base != nullptr;
+	const uint32_t strip_bytes = (uint32_t)(a.strips.frame_words * 4);
+	const __amdgpu_buffer_rsrc_t rs_strip = __builtin_amdgcn_make_buffer_rsrc(use_strips ? a.strips.base + (size_t)f * a.strips.frame_words : const_cast<uint32_t*>(in + frame), 0,
+			(int)(use_strips ? strip_bytes : frame_bytes), 0x00020000);
+
+	// ---- register image of the next tile: NI x 16 B of interior + NHS dwords of halo per side ------------------------------
+	typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+	v4u pv0, pv1, pv2, pv3, pv4;
+	uint32_t hl0 = 0, hl1 = 0, hr0 = 0, hr1 = 0;
+	// The index constants of the prefetch (c4, r16, halo row / column) are recomputed from an opaque copy of tid wherever they
+	// are used: hoisted out of the tile loop they would occupy ~10 VGPRs for the whole kernel.
+	int tidv = tid;
+#define VP2_IDX()                                                                                          \
+	asm volatile("" : "+v"(tidv));                                                                         \
+	const int c4 = tidv & 15, r16 = tidv >> 4;                                                             \
+	/* halo element i of a side: row i / O, column k = i % O (compile-time O) */                           \
+	const int hi0 = min(tidv, ROWS * O - 1), hi1 = min(tidv + 256, ROWS * O - 1);                          \
+	const int hrow0 = hi0 / O, hk0 = hi0 - hrow0 * O, hrow1 = hi1 / O, hk1 = hi1 - hrow1 * O;              \
+	(void)hrow1; (void)hk1
+	auto clamp_row = [&](int Y0, int row) { return (uint32_t)vp_clampi(Y0 - O + row, 0, h - 1); };
+	auto tile_load = [&](int P, int X0, int Y0, int c4, int r16) {
+		const uint32_t voff = clamp_row(Y0, min(r16 + 16 * P, ROWS - 1)) * row_bytes + 16u * (uint32_t)c4;
+		return __builtin_amdgcn_raw_buffer_load_b128(rs_flat, voff, (uint32_t)X0 * 4u, 2); // aux 2 = nt: read once
+	};
+	// left side: pixels X0 - O + k; right side: X0 + 64 + k (clamp-to-edge at the image border, gradientDot.cl:20)
+	auto halo_load = [&](bool right, int row, int k, int X0, int Y0) -> uint32_t {
+		const uint32_t gy = clamp_row(Y0, row);
+		const int tjx = X0 >> 6;
+		const bool border = right ? tjx + 1 >= a.tilesX : tjx == 0;
+		if(use_strips && !border) { // neighbour tile's edge record: rec(j, gy, e) = ((j * h + gy) * 2 O + e)
+			const int j = right ? tjx + 1 : tjx - 1;
+			return __builtin_amdgcn_raw_buffer_load_b32(rs_strip, (gy * (2u * O) + (uint32_t)(right ? k : O + k)) * 4u, (uint32_t)j * (uint32_t)h * (2u * O) * 4u, 0);
+		}
+		if(border) return __builtin_amdgcn_raw_buffer_load_b32(rs_flat, gy * row_bytes, right ? row_bytes - 4u : 0u, 0); // edge column replicated
+		return __builtin_amdgcn_raw_buffer_load_b32(rs_flat, gy * row_bytes + 4u * (uint32_t)k, (uint32_t)(right ? X0 + TW : X0 - O) * 4u, 0);
+	};
+#define VP2_PREFETCH(X0, Y0)                                           \
+	do {                                                                 \
+		VP2_IDX();                                                       \
+		pv0 = tile_load(0, X0, Y0, c4, r16);                             \
+		pv1 = tile_load(1, X0, Y0, c4, r16);                             \
+		pv2 = tile_load(2, X0, Y0, c4, r16);                             \
+		pv3 = tile_load(3, X0, Y0, c4, r16);                             \
+		if(NI > 4) pv4 = tile_load(4, X0, Y0, c4, r16);                  \
+		hl0 = halo_load(false, hrow0, hk0, X0, Y0);                      \
+		hr0 = halo_load(true, hrow0, hk0, X0, Y0);                       \
+		if(NHS > 1) {                                                    \
+			hl1 = halo_load(false, hrow1, hk1, X0, Y0);                  \
+			hr1 = halo_load(true, hrow1, hk1, X0, Y0);                   \
+		}                                                                \
+	} while(0)
+#define VP2_COMMIT_ROW(P, V)                                                                                          \
+	do {                                                                                                                \
+		if(r16 + 16 * (P) < ROWS) *reinterpret_cast<v4u*>(raw + (r16 + 16 * (P)) * PITCH + 4 + 4 * c4) = (V);           \
+	} while(0)
+#define VP2_COMMIT_ALL()                                                                     \
+	do {                                                                                       \
+		VP2_IDX();                                                                             \
+		VP2_COMMIT_ROW(0, pv0);                                                                \
+		VP2_COMMIT_ROW(1, pv1);                                                                \
+		VP2_COMMIT_ROW(2, pv2);                                                                \
+		VP2_COMMIT_ROW(3, pv3);                                                                \
+		if(NI > 4) VP2_COMMIT_ROW(4, pv4);                                                     \
+		if(tidv < ROWS * O) {                                                                  \
+			raw[hrow0 * PITCH + 4 - O + hk0] = hl0;                                            \
+			raw[hrow0 * PITCH + 4 + TW + hk0] = hr0;                                           \
+		}                                                                                      \
+		if(NHS > 1 && tidv + 256 < ROWS * O) {                                                 \
+			raw[hrow1 * PITCH + 4 - O + hk1] = hl1;                                            \
+			raw[hrow1 * PITCH + 4 + TW + hk1] = hr1;                                           \
+		}                                                                                      \
+	} while(0)
+	pv4 = v4u{0, 0, 0, 0};
+	{
+		const uint32_t t0 = a.order[__builtin_amdgcn_readfirstlane(rem)];
+		VP2_PREFETCH((int)(t0 & 0xFFFF) * TW, (int)(t0 >> 16) * TH);
+	}
+
+	// phase B / E mapping: lane = 16 ql + m, columns 4m..4m+3, rows 16 wv + 4 q + it (q = bit-reversed ql: see k_sat_fast)
+	const int m = lane & 15, ql = lane >> 4, q = ((ql & 1) << 1) | (ql >> 1);
+	const int sg_mine = 4 * wv + q;
+	const uint32_t out_voff = ((uint32_t)(16 * wv + 4 * q) * (uint32_t)w + 4u * (uint32_t)m) * 4u;
+
+	for(;;) {
+		const uint32_t tcur = a.order[__builtin_amdgcn_readfirstlane(rem)];
+		const int ti = (int)(tcur >> 16), tj = (int)(tcur & 0xFFFF);
+		const int x0 = tj * TW, y0 = ti * TH;
+
+		// ---- A: registers -> LDS; publish the next ticket, request the one after --------------------------------------
+		VP2_COMMIT_ALL();
+		if(loader) misc[3] = (int)(pending - a.ticket_base);
+		lds_barrier();
+		if(loader) pending = atomicAdd(queue, 1u);
+		const int next = misc[3];
+		const bool more = next >= 0 && next < perFrame;
+
+		// early polls: the carries of the two nearest predecessors of each chain, requested before our own sums exist
+		const size_t tile = (size_t)f * perFrame + (size_t)ti * a.tilesX + tj;
+		u64 pre0 = 0, pre1 = 0;
+		int lanev = lane; // opaque copy: lane-dependent 64-bit granule pointers must not be hoisted out of the tile loop (4 VGPRs each)
+		asm volatile("" : "+v"(lanev));
+		if(wv == 0 && ti > 0) {
+			const u64* g = a.V + tile * TW + lanev;
+			pre0 = ld_granule(g - (long)a.tilesX * TW);
+			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX * TW);
+		} else if(wv == 1 && tj > 0) {
+			const u64* g = a.H + tile * TH + lanev;
+			pre0 = ld_granule(g - TH);
+			if(tj > 1) pre1 = ld_granule(g - 2 * TH);
+		} else if(wv == 2 && ti > 0) {
+			const u64* g = a.K + tile;
+			pre0 = ld_granule(g - a.tilesX);
+			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX);
+		}
+
+		// ---- B: local SAT of the lane's 4 x 4 pixels, kept in registers -------------------------------------------------
+		int4 sres[4];
+		{
+			int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
+#pragma unroll
+			for(int it = 0; it < 4; it++) {
+				const int r = 16 * wv + 4 * q + it;
+				const uint32_t* c = raw + (r + O) * PITCH + 4 + 4 * m;
+				const uint4 L = *reinterpret_cast<const uint4*>(c - 4), C = *reinterpret_cast<const uint4*>(c), R = *reinterpret_cast<const uint4*>(c + 4);
+				const uint4 U = *reinterpret_cast<const uint4*>(c - O * PITCH), D = *reinterpret_cast<const uint4*>(c + O * PITCH);
+				const uint32_t hx[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
+				int g0 = grad_dot_pk(hx[4 + O], hx[4 - O], D.x, U.x);
+				int g1 = grad_dot_pk(hx[5 + O], hx[5 - O], D.y, U.y);
+				int g2 = grad_dot_pk(hx[6 + O], hx[6 - O], D.z, U.z);
+				int g3 = grad_dot_pk(hx[7 + O], hx[7 - O], D.w, U.w);
+				const bool yin = y0 + r < h;
+				if(!yin) g0 = g1 = g2 = g3 = 0;
+				if(gd_out && yin) *reinterpret_cast<float4*>(gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
+				g1 += g0;
+				g2 += g1;
+				g3 += g2;
+				int sc = g3; // inclusive scan of the lane totals over the 16 lanes of this row
+				sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xf, 0xf, false);
+				sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xf, 0xf, false);
+				sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xf, 0xf, false);
+				sc += __builtin_amdgcn_update_dpp(0, sc, 0x118, 0xf, 0xf, false);
+				const int ex = sc - g3;
+				run0 += g0 + ex;
+				run1 += g1 + ex;
+				run2 += g2 + ex;
+				run3 += g3 + ex;
+				sres[it] = make_int4(run0, run1, run2, run3);
+				if(m == 15) Rc[r] = run3;
+				__builtin_amdgcn_sched_barrier(0); // one row at a time: overlapping the taps of several rows costs ~20 VGPRs
+			}
+			*reinterpret_cast<int4*>(T16 + sg_mine * TW + 4 * m) = make_int4(run0, run1, run2, run3);
+		}
+		lds_barrier();
+
+		// ---- C/D: aggregates, publication, look-back (as k_sat_fast) -----------------------------------------------------
+		if(wv == 0) {
+			int pc = 0;
+#pragma unroll
+			for(int sg = 0; sg < 16; sg++) pc += T16[sg * TW + lane];
+			asm volatile("" : "+v"(lanev));
+			u64* g = a.V + tile * TW + lanev;
+			int carry = 0;
+			if(ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) {
+				st_granule(g, a.epoch, ST_AGG, pc);
+				lookback<false>(g, (long)a.tilesX * TW, ti, a, carry);
+			}
+			st_granule(g, a.epoch, ST_INC, carry + pc);
+			Av[lane] = carry;
+		} else if(wv == 1) {
+			const int t = T16[(lane >> 2) * TW + TW - 1];
+			const int pr = Rc[lane] + scan_incl_dpp((lane & 3) == 0 ? t : 0) - t;
+			asm volatile("" : "+v"(lanev));
+			u64* g = a.H + tile * TH + lanev;
+			int carry = 0;
+			if(tj > 0 && !early_resolve(pre0, pre1, tj, a, carry)) {
+				st_granule(g, a.epoch, ST_AGG, pr);
+				lookback<false>(g, TH, tj, a, carry);
+			}
+			st_granule(g, a.epoch, ST_INC, carry + pr);
+			Bv[lane] = carry;
+			if(lane == TH - 1) {
+				misc[2] = carry;
+				st_granule(a.K + tile, a.epoch, ti > 0 ? ST_AGG : ST_INC, carry);
+			}
+		} else if(wv == 2) {
+			int carry = 0;
+			if(ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback<false>(a.K + tile, a.tilesX, ti, a, carry);
+			if(lane == 0) misc[1] = carry;
+		} else { // wave 3 has no chain: it turns the sub-segment totals into their exclusive prefix for phase E
+			int acc = 0;
+#pragma unroll
+			for(int sg = 0; sg < 16; sg++) {
+				T16P[sg * TW + lane] = acc;
+				acc += T16[sg * TW + lane];
+			}
+		}
+		lds_barrier();
+		const int K = misc[1];
+		if(wv == 1 && lane == 0 && ti > 0) st_granule(a.K + tile, a.epoch, ST_INC, K + misc[2]);
+		if(more) { // next tile -> registers: in flight across phase E and the loop barrier
+			const uint32_t tn = a.order[__builtin_amdgcn_readfirstlane(next)];
+			VP2_PREFETCH((int)(tn & 0xFFFF) * TW, (int)(tn >> 16) * TH);
+		}
+
+		// ---- E: out = local + (sub-segment totals above) + A(x) + B(y) + K, for the lane's own 16 pixels --------------------
+		{
+			const int4 av = *reinterpret_cast<const int4*>(Av + 4 * m);
+			int4 add = make_int4(av.x + K, av.y + K, av.z + K, av.w + K);
+			{
+				const int4 t = *reinterpret_cast<const int4*>(T16P + sg_mine * TW + 4 * m);
+				add = make_int4(add.x + t.x, add.y + t.y, add.z + t.z, add.w + t.w);
+			}
+			const uint32_t tile_off = ((uint32_t)y0 * (uint32_t)w + (uint32_t)x0) * 4u;
+			typedef int v4i __attribute__((ext_vector_type(4)));
+#pragma unroll
+			for(int it = 0; it < 4; it++) {
+				const int r = 16 * wv + 4 * q + it;
+				const int b = Bv[r];
+				const v4i o4 = {sres[it].x + add.x + b, sres[it].y + add.y + b, sres[it].z + add.z + b, sres[it].w + add.w + b};
+				if(y0 + r < h) __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, out_voff + (uint32_t)it * row_bytes, tile_off, 2); // nt: streamed out
+			}
+		}
+		if(!more) break;
+		rem = next;
+		lds_barrier(); // T16 / Rc / Av / Bv / misc of this tile are dead only now (phase E read them)
+	}
+#undef VP2_IDX
+#undef VP2_PREFETCH
+#undef VP2_COMMIT_ROW
+#undef VP2_COMMIT_ALL
+}
+
 } // namespace
 
 int vp_check_timeout(VpContext* ctx, int stream);
@@ -789,7 +1072,13 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 
 	// persistent grid: P workgroups per frame queue; every workgroup overshoots its queue by exactly two tickets
 	const int perFrame = a.tilesX * a.tilesY;
-	int P = (4 * ctx->cu_count + batch - 1) / batch;
+	// k_sat_fast2 keeps VP_SAT_WPC (5 or 6) workgroups per CU resident, k_sat_fast 4
+	const int v2_wpc = getenv("VP_SAT_WPC") ? atoi(getenv("VP_SAT_WPC")) : 5;
+	const bool fast_ok = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
+			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0);
+	const bool v2 = fast_ok && !(getenv("VP_SAT_V2") && atoi(getenv("VP_SAT_V2")) == 0) && !getenv("VP_SAT_DEBUG") && (size_t)w * h * 4 < 0x7fffffffu &&
+			(size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu && (v2_wpc == 5 || v2_wpc == 6);
+	int P = ((v2 ? v2_wpc : 4) * ctx->cu_count + batch - 1) / batch;
 	if(P < 1) P = 1;
 	if(P > perFrame) P = perFrame;
 	ctx->sat_ticket_base[stream] += (uint32_t)(perFrame + 2 * P);
@@ -797,7 +1086,20 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	const bool pipe = fused && o >= 1 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !(a.debug & 2);
 	const bool fast = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
 			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0) && !(a.debug & 16);
-	if(fast) {
+	if(v2) {
+		const size_t lds2 = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + 32 * TW + TH + TW + TH + 8);
+		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
+#define VP_FAST2(OO) \
+		do { \
+			if(v2_wpc == 6) k_sat_fast2<OO, 6><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else k_sat_fast2<OO, 5><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+		} while(0)
+		if(o == 1) VP_FAST2(1);
+		else if(o == 2) VP_FAST2(2);
+		else if(o == 3) VP_FAST2(3);
+		else VP_FAST2(4);
+#undef VP_FAST2
+	} else if(fast) {
 		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8 + (o <= 2 ? 16 * TW : 0) + TH);
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
 #define VP_FAST(OO) \
