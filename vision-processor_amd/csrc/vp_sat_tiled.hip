@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 //     arithmetic, no divisions in the loop: the register peak of k_sat_fast sat in exactly that code);
 // which brings a workgroup to 24.6 KB of LDS and <= WPC-dependent VGPR budget: WPC = 5 or 6 workgroups per CU.
 // Works for every O in 1..4 (nothing aliases the raw tile).  Same granule protocol, same tile order, same results.
-template<int O, int WPC>
+template<int O, int WPC, bool GD>
 __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
 	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
 	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
@@ -858,6 +858,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 		}
 
 		// ---- B: local SAT of the lane's 4 x 4 pixels, kept in registers -------------------------------------------------
+		const bool bottom = y0 + TH > h;
 		int4 sres[4];
 		{
 			int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
@@ -872,9 +873,10 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 				int g1 = grad_dot_pk(hx[5 + O], hx[5 - O], D.y, U.y);
 				int g2 = grad_dot_pk(hx[6 + O], hx[6 - O], D.z, U.z);
 				int g3 = grad_dot_pk(hx[7 + O], hx[7 - O], D.w, U.w);
-				const bool yin = y0 + r < h;
-				if(!yin) g0 = g1 = g2 = g3 = 0;
-				if(gd_out && yin) *reinterpret_cast<float4*>(gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
+				if(bottom) { // only tiles that overhang the image mask rows (workgroup-uniform)
+					if(y0 + r >= h) g0 = g1 = g2 = g3 = 0;
+				}
+				if(GD && y0 + r < h) *reinterpret_cast<float4*>(gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
 				g1 += g0;
 				g2 += g1;
 				g3 += g2;
@@ -1091,8 +1093,9 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
 #define VP_FAST2(OO) \
 		do { \
-			if(v2_wpc == 6) k_sat_fast2<OO, 6><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
-			else k_sat_fast2<OO, 5><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			if(graddot_out) k_sat_fast2<OO, 5, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else if(v2_wpc == 6) k_sat_fast2<OO, 6, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else k_sat_fast2<OO, 5, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 		} while(0)
 		if(o == 1) VP_FAST2(1);
 		else if(o == 2) VP_FAST2(2);
