@@ -1079,7 +1079,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	const bool fast_ok = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
 			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0);
 	const bool v2 = fast_ok && !(getenv("VP_SAT_V2") && atoi(getenv("VP_SAT_V2")) == 0) && !getenv("VP_SAT_DEBUG") && (size_t)w * h * 4 < 0x7fffffffu &&
-			(size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu && (v2_wpc == 5 || v2_wpc == 6);
+			(size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu && (v2_wpc >= 2 && v2_wpc <= 8);
 	int P = ((v2 ? v2_wpc : 4) * ctx->cu_count + batch - 1) / batch;
 	if(P < 1) P = 1;
 	if(P > perFrame) P = perFrame;
