@@ -308,6 +308,43 @@ def test_colour_kernels_batches_and_odd_heights(gpu, port):
         assert np.array_equal(host(d_nv[i]), port.f2nv12(f[i]))
 
 
+@pytest.mark.parametrize("shape", [(64, 5), (64, 64), (128, 70), (192, 129), (256, 63)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("o", [1, 2, 3, 4])
+def test_fast_sat_edge_shapes(gpu, port, shape, o):
+    """The single-pass fast kernels on awkward shapes: one tile column, fewer rows than the halo, heights that overhang the last
+    tile row, with and without edge records, with and without the gradDot view."""
+    capi, ctx, torch = gpu
+    w, h = shape
+    rng = np.random.default_rng(w * 1000 + h * 10 + o)
+    B = 3
+    flat = rng.integers(0, 256, (B, h, w, 4), dtype=np.uint8)
+    flat[..., 3] = 255
+    d_flat = dev(torch, flat)
+    want_gd = [port.graddot(flat[i], o) for i in range(B)]
+    want_sat = [g.astype(np.int64).cumsum(0).cumsum(1).astype(np.int32) for g in want_gd]
+    nbytes = ctx.halo_strip_bytes(w, h, o)
+    assert nbytes > 0
+    d_strips = torch.zeros((B, nbytes // 4), dtype=torch.int32, device="cuda")
+    ctx.halo_strips(d_flat, w, h, o, B, d_strips)
+    import os
+    for gen, with_strips, with_gd in [(g, s_, d) for g in ("1", "0") for s_ in (False, True) for d in (False, True)]:
+        os.environ["VP_SAT_V2"] = gen  # both generations of the fast kernel (read by the library at every launch)
+        try:
+            d_sat = torch.full((B, h, w), -7, dtype=torch.int32, device="cuda")
+            d_gd = torch.zeros((B, h, w), dtype=torch.float32, device="cuda") if with_gd else None
+            if with_strips:
+                ctx.graddot_sat_strips(d_flat, d_strips, w, h, o, B, capi.SAT_TILED, d_sat, d_gd)
+            else:
+                ctx.graddot_sat(d_flat, w, h, o, B, capi.SAT_TILED, d_sat, d_gd)
+            ctx.sync()
+        finally:
+            os.environ.pop("VP_SAT_V2", None)
+        for i in range(B):
+            assert np.array_equal(host(d_sat[i]), want_sat[i]), (gen, with_strips, with_gd, i)
+            if with_gd:
+                assert np.array_equal(host(d_gd[i]), want_gd[i])
+
+
 def test_full_size_properties(gpu, port):
     """BASELINE.json configs[1] (2048x1536): properties that do not need a full CPU reference run per frame."""
     capi, ctx, torch = gpu
