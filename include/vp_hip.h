@@ -146,13 +146,13 @@ int vp_sat(VpContext* ctx, int stream, const float* graddot, int w, int h, int b
 int vp_graddot_sat(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, int variant,
 		int32_t* sat, float* graddot_out);
 
-/* Halo strips: the first and the last `offset` flat pixels of every 64-pixel tile row, compacted into one edge record of
- * 2*offset RGBA8 pixels per (tile column, row): [tile column][row][first offset pixels | last offset pixels].  The single-pass
- * SAT needs an `offset` wide horizontal halo on both sides of a tile; fetched from `flat` that halo costs one 128-byte line per
- * row and side (measured: 1.51x the algorithmic bytes of the pass), fetched from the neighbours' records it is dense (1.18x).
- * vp_frame lets the resampling kernel emit the records while it writes flat (one masked store per 64-pixel row); vp_halo_strips
- * builds them from an existing flat.  Requires w % 64 == 0 and 1 <= offset <= 4 (vp_halo_strip_bytes returns 0 otherwise and
- * the strips are simply not used).  Size per frame: 2 * (w / 64) * h * offset * 4 bytes. */
+/* Halo strips: the first and the last `offset` flat pixels of every 64-pixel tile row, in two dense arrays per frame:
+ * FIRST[tile column][row][offset] followed by LAST[tile column][row][offset].  The single-pass SAT needs an `offset` wide
+ * horizontal halo on both sides of a tile; fetched from `flat` that halo costs one 128-byte line per row and side (measured:
+ * 1.51x the algorithmic bytes of the pass), fetched from the neighbours' arrays it is dense (1.16x).  vp_frame lets the
+ * resampling kernel emit both arrays while it writes flat (one masked store per 64-pixel row); vp_halo_strips builds them from
+ * an existing flat.  Requires w % 64 == 0 and 1 <= offset <= 4 (vp_halo_strip_bytes returns 0 otherwise and the strips are
+ * simply not used).  Size per frame: 2 * (w / 64) * h * offset * 4 bytes. */
 size_t vp_halo_strip_bytes(int w, int h, int offset);
 int vp_halo_strips(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, uint32_t* strips);
 int vp_graddot_sat_strips(VpContext* ctx, int stream, const uint8_t* flat, const uint32_t* strips, int w, int h, int offset, int batch, int variant,

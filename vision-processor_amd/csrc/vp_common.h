@@ -112,15 +112,18 @@ static inline int vp_launch_ok(const char* what) {
 
 static inline unsigned vp_div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-// Halo strips (include/vp_hip.h): per frame one EDGE RECORD of 2*offset RGBA8 pixels per (64-pixel tile column j, row y):
-// [first `offset` pixels of the tile row | last `offset` pixels], i.e. flat[y][64 j + k] and flat[y][64 j + 64 - offset + k].
-// The wavefront that produces a 64-pixel tile row writes its record with ONE masked store.  A SAT tile takes its left halo
-// from the upper half of its left neighbour's record and its right halo from the lower half of its right neighbour's.
+// Halo strips (include/vp_hip.h): per frame the first and the last `offset` RGBA8 pixels of every 64-pixel tile row, in two
+// dense arrays FIRST[tile column j][row y][k] = flat[y][64 j + k] and LAST[j][y][k] = flat[y][64 j + 64 - offset + k] (LAST
+// follows FIRST).  The wavefront that produces a 64-pixel tile row writes both with ONE masked store (per-lane offsets).  A
+// SAT tile takes its left halo from LAST of its left neighbour and its right halo from FIRST of its right neighbour: both are
+// contiguous over rows, so every fetched line is used whole.
 struct VpStrips {
 	uint32_t* base;       // nullptr: not in use
 	int tiles_x, h, o;
 	size_t frame_words;   // uint32 per frame = 2 * tiles_x * h * o
-	__host__ __device__ size_t rec(int j, int y, int e) const { return ((size_t)j * h + y) * (2 * o) + e; }
+	__host__ __device__ size_t rec(int j, int y, int e) const { // e < o: FIRST, else LAST
+		return e < o ? ((size_t)j * h + y) * o + e : ((size_t)(tiles_x + j) * h + y) * o + (e - o);
+	}
 	__host__ __device__ size_t left(int b, int y, int k) const { return rec(b - 1, y, o + k); } // flat[y][64 b - o + k], b >= 1
 	__host__ __device__ size_t right(int b, int y, int k) const { return rec(b, y, k); }        // flat[y][64 b + k]
 };

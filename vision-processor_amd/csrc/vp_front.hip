@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			const int xm = gx & 63, tb = gx >> 6;
 			const uint32_t so = (uint32_t)strips.o, sh = (uint32_t)strips.h; // VpStrips::rec in 32-bit arithmetic (frame_words * 4 < 2 GiB)
 			const bool se = valid && strips.base && (xm < strips.o || xm >= 64 - strips.o); // this pixel belongs to its tile row's edge record
-			const uint32_t voff_se = se ? 4u * ((((uint32_t)tb * sh + (uint32_t)gy) * 2u * so) + (uint32_t)(xm < strips.o ? xm : xm - 64 + 2 * strips.o)) : 0u;
+			const uint32_t voff_se = se ? 4u * (xm < strips.o ? ((uint32_t)tb * sh + (uint32_t)gy) * so + (uint32_t)xm
+			                                                   : ((uint32_t)(strips.tiles_x + tb) * sh + (uint32_t)gy) * so + (uint32_t)(xm - 64) + so) : 0u;
 			const int wcol = g.d0 - cmin;
 			const int ie0 = (g.re0 - rmin) * wdw + wcol, ie1 = (g.re1 - rmin) * wdw + wcol, io0 = (g.ro0 - rmin) * wdw + wcol, io1 = (g.ro1 - rmin) * wdw + wcol;
 			// which dwords of the box this thread fetches, NP pieces of 256 (lanes past the box re-fetch its first dword: harmless)
