@@ -257,6 +257,7 @@ struct Bayer4Stage {
 	int re0, re1, ro0, ro1;  // sensor rows of the four windows
 	uint32_t sel;            // perm selector: bytes [a.i0, a.i1, b.i0, b.i1]
 	float xa, xb, ya, yb;
+	int ia0, ia1, ib0, ib1;  // the four cell columns themselves (float-staged variant)
 };
 __device__ __forceinline__ Bayer4Stage bayer4_stage(float px, float py, int qw, int qh) {
 	const Axis xa = axis_lin(px + 0.25f, qw), xb = axis_lin(px - 0.25f, qw);
@@ -266,6 +267,10 @@ __device__ __forceinline__ Bayer4Stage bayer4_stage(float px, float py, int qw, 
 	g.d0 = min((2 * min(xa.i0, xb.i0)) >> 2, (qw >> 1) - 2);
 	const int b0 = 4 * g.d0;
 	g.sel = (uint32_t)(2 * xa.i0 - b0) | ((uint32_t)(2 * xa.i1 - b0) << 8) | ((uint32_t)(2 * xb.i0 + 1 - b0) << 16) | ((uint32_t)(2 * xb.i1 + 1 - b0) << 24);
+	g.ia0 = xa.i0;
+	g.ia1 = xa.i1;
+	g.ib0 = xb.i0;
+	g.ib1 = xb.i1;
 	g.re0 = 2 * ya.i0;
 	g.re1 = 2 * ya.i1;
 	g.ro0 = 2 * yb.i0 + 1;
@@ -386,7 +391,7 @@ __device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
 
 // Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
 // sample directly (bayer4_eval); results are identical either way.
-template<int LAYOUT>
+template<int LAYOUT, bool FLT>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
 	__shared__ uint32_t stage[RESAMPLE_FPT][STAGE_DW];
@@ -475,7 +480,53 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
 				}
 			};
-			if(ndw <= 256) run(std::integral_constant<int, 1>());
+			// FLT: the box is staged as FLOATS, one frame at a time (double buffered, one barrier per frame): every texel is
+			// converted once by the thread that fetched it (4 converts per thread and frame) instead of once per use (16 per pixel
+			// and frame, at the 4-cycle rate).  Even sensor columns go to plane A, odd ones to plane B of a box row, so the two
+			// texels of a footprint row are neighbours.  Loads of all frames are still issued up front.
+			auto run_flt = [&]() {
+				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][1024]
+				const int own = tid < ndw ? tid : 0, orow = (int)(((float)own + 0.5f) * inv_wdw), ocol = own - orow * wdw;
+				const uint32_t goff = (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol);
+				const int RP = 4 * wdw; // floats per box row: [A: 2 wdw | B: 2 wdw]
+				float* wa = F + orow * RP + 2 * ocol;
+				float* wb = wa + 2 * wdw;
+				uint32_t pre[RESAMPLE_FPT];
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff, (uint32_t)min(j, nf - 1) * fb_raw, 0);
+				auto put = [&](int buf, uint32_t v) {
+					if(tid < ndw) {
+						*reinterpret_cast<float2*>(wa + buf * 1024) = make_float2((float)(v & 0xFF), (float)((v >> 16) & 0xFF));
+						*reinterpret_cast<float2*>(wb + buf * 1024) = make_float2((float)((v >> 8) & 0xFF), (float)(v >> 24));
+					}
+				};
+				// float indices of the 16 texels (frame independent): plane A column of cell i is i - 2 cmin, plane B likewise + 2 wdw
+				const int ca0 = g.ia0 - 2 * cmin, ca1 = g.ia1 - 2 * cmin, cb0 = g.ib0 - 2 * cmin + 2 * wdw, cb1 = g.ib1 - 2 * cmin + 2 * wdw;
+				const int r0 = (g.re0 - rmin) * RP, r1 = (g.re1 - rmin) * RP, r2 = (g.ro0 - rmin) * RP, r3 = (g.ro1 - rmin) * RP;
+				const float* t00 = F + r0 + ca0; const float* t01 = F + r0 + ca1; const float* t02 = F + r1 + ca0; const float* t03 = F + r1 + ca1;
+				const float* t10 = F + r0 + cb0; const float* t11 = F + r0 + cb1; const float* t12 = F + r1 + cb0; const float* t13 = F + r1 + cb1;
+				const float* t20 = F + r2 + ca0; const float* t21 = F + r2 + ca1; const float* t22 = F + r3 + ca0; const float* t23 = F + r3 + ca1;
+				const float* t30 = F + r2 + cb0; const float* t31 = F + r2 + cb1; const float* t32 = F + r3 + cb0; const float* t33 = F + r3 + cb1;
+				put(0, pre[0]);
+				__syncthreads();
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) {
+					if(j >= nf) break;
+					const int o = (j & 1) * 1024; // compile-time after unrolling: folds into the ds_read offset field
+					uint32_t p[4];
+					p[0] = bilin(t00[o], t01[o], t02[o], t03[o], g.xa, g.ya);
+					p[1] = bilin(t10[o], t11[o], t12[o], t13[o], g.xb, g.ya);
+					p[2] = bilin(t20[o], t21[o], t22[o], t23[o], g.xa, g.yb);
+					p[3] = bilin(t30[o], t31[o], t32[o], t33[o], g.xb, g.yb);
+					if(j + 1 < nf) put((j + 1) & 1, pre[j + 1 < RESAMPLE_FPT ? j + 1 : j]);
+					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
+					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
+					__syncthreads(); // frame j+1 is staged; everybody is done reading frame j's buffer before frame j+2 overwrites it
+				}
+			};
+			if(FLT) run_flt();
+			else if(ndw <= 256) run(std::integral_constant<int, 1>());
 			else run(std::integral_constant<int, STAGE_DW / 256>());
 			return;
 		}
@@ -591,8 +642,14 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	if(layout != VP_LAYOUT_BGR && sampler_mode == VP_SAMPLER_BILINEAR_RTZ && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
 			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
 		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
-		if(layout == VP_LAYOUT_RGGB) k_resample_staged<VP_LAYOUT_RGGB><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
-		else k_resample_staged<VP_LAYOUT_GRBG><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		const bool flt = !(getenv("VP_RS_FLT") && atoi(getenv("VP_RS_FLT")) == 0); // float-staged variant (default; VP_RS_FLT=0 selects the byte-staged one for A/B)
+		if(layout == VP_LAYOUT_RGGB) {
+			if(flt) k_resample_staged<VP_LAYOUT_RGGB, true><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+			else k_resample_staged<VP_LAYOUT_RGGB, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		} else {
+			if(flt) k_resample_staged<VP_LAYOUT_GRBG, true><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+			else k_resample_staged<VP_LAYOUT_GRBG, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		}
 		return vp_launch_ok("raw2quad+resampling (staged)");
 	}
 #define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch)
