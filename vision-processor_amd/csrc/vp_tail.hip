@@ -212,21 +212,8 @@ __global__ __launch_bounds__(256) void k_rank_scatter(const uint8_t* __restrict_
 		uint16_t* dst = reinterpret_cast<uint16_t*>(rec_tmp + ((size_t)z * max_matches + rank) * 22);
 #pragma unroll
 		for(int k = 0; k < 11; k++) dst[k] = src[k];
-		idx_tmp[(size_t)z * max_matches + rank] = mine;
+		if(idx_tmp) idx_tmp[(size_t)z * max_matches + rank] = mine;
 	}
-}
-
-__global__ __launch_bounds__(256) void k_copy_back(const uint8_t* __restrict__ rec_tmp, const uint32_t* __restrict__ idx_tmp, const int32_t* __restrict__ counter,
-		uint8_t* __restrict__ rec, uint32_t* __restrict__ idx, int max_matches) {
-	const int z = blockIdx.y;
-	const int n = min(counter[3 * z], max_matches);
-	const int t = blockIdx.x * 256 + threadIdx.x;
-	if(t >= n) return;
-	const uint16_t* src = reinterpret_cast<const uint16_t*>(rec_tmp + ((size_t)z * max_matches + t) * 22);
-	uint16_t* dst = reinterpret_cast<uint16_t*>(rec + ((size_t)z * max_matches + t) * 22);
-#pragma unroll
-	for(int k = 0; k < 11; k++) dst[k] = src[k];
-	if(idx) idx[(size_t)z * max_matches + t] = idx_tmp[(size_t)z * max_matches + t];
 }
 
 // circle + detect fused: the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge addressing (satBlobCenter.cl:20, H7),
@@ -421,10 +408,12 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 	VP_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t) * 3 * batch, s)); // main.cpp:283-288
 	VP_CHECK_HIP(hipMemsetAsync(ws.cand_count, 0, sizeof(int32_t) * batch, s));
 	uint32_t* idx_work = (order == VP_ORDER_RASTER || !idx) ? ws.idx : idx;
+	// RASTER order: the emit kernels append into workspace records, k_rank_scatter sorts them straight into the caller's arrays
+	uint8_t* rec_work = order == VP_ORDER_RASTER ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
 	if(blobcenter) {
 		k_detect<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, s>>>(blobcenter, ws.cand, ws.cand_count, counter, w, h, thr);
 		VP_TRY(vp_launch_ok("blobList detect"));
-		k_emit<false><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
+		k_emit<false><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, counter, rec_work, idx_work,
 				w, h, min_score, radius, max_matches, 0);
 	} else {
 		const int halo = circle_radius + 1;
@@ -451,16 +440,14 @@ static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat,
 #undef VP_CD_R
 #undef VP_CD
 		VP_TRY(vp_launch_ok("circle+detect"));
-		k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, counter, reinterpret_cast<uint8_t*>(matches), idx_work,
+		k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, counter, rec_work, idx_work,
 				w, h, min_score, radius, max_matches, circle_radius);
 	}
 	VP_TRY(vp_launch_ok("blobList emit"));
 	if(order == VP_ORDER_RASTER) {
 		const dim3 grid(vp_div_up(max_matches, 256), batch);
-		k_rank_scatter<<<grid, 256, 0, s>>>(reinterpret_cast<const uint8_t*>(matches), ws.idx, counter, ws.rec_tmp, ws.idx_tmp, max_matches);
+		k_rank_scatter<<<grid, 256, 0, s>>>(ws.rec_tmp, ws.idx, counter, reinterpret_cast<uint8_t*>(matches), idx, max_matches);
 		VP_TRY(vp_launch_ok("blobList rank"));
-		k_copy_back<<<grid, 256, 0, s>>>(ws.rec_tmp, ws.idx_tmp, counter, reinterpret_cast<uint8_t*>(matches), idx, max_matches);
-		VP_TRY(vp_launch_ok("blobList copy"));
 	}
 	return VP_OK;
 }
