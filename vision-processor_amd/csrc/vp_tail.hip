@@ -216,6 +216,12 @@ __global__ __launch_bounds__(256) void k_rank_scatter(const uint8_t* __restrict_
 	}
 }
 
+__global__ __launch_bounds__(256) void k_zero2(int32_t* __restrict__ a, int na, int32_t* __restrict__ b, int nb) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if(i < na) a[i] = 0;
+	if(i < nb) b[i] = 0;
+}
+
 // circle + detect fused: the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge addressing (satBlobCenter.cl:20, H7),
 // blobCenter is computed for the 64x64 tile plus a 1-pixel ring into LDS, then thresholded / peak-tested (blobList.cl:37-55).
 // Out-of-image ring positions take the value of the clamped position, exactly what the clamped reads of the reference return.
@@ -405,8 +411,10 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
 		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, const ListScratch& ws) {
 	hipStream_t s = ctx->streams[stream];
-	VP_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t) * 3 * batch, s)); // main.cpp:283-288
-	VP_CHECK_HIP(hipMemsetAsync(ws.cand_count, 0, sizeof(int32_t) * batch, s));
+	// main.cpp:283-288: the host zeroes counter[3] before every launch; here one small kernel clears it and the candidate counters
+	// (two hipMemsetAsync calls cost ~10 us each)
+	k_zero2<<<vp_div_up(3 * batch, 256), 256, 0, s>>>(counter, 3 * batch, ws.cand_count, batch);
+	VP_TRY(vp_launch_ok("blobList counters"));
 	uint32_t* idx_work = (order == VP_ORDER_RASTER || !idx) ? ws.idx : idx;
 	// RASTER order: the emit kernels append into workspace records, k_rank_scatter sorts them straight into the caller's arrays
 	uint8_t* rec_work = order == VP_ORDER_RASTER ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
