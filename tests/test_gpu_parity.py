@@ -312,7 +312,7 @@ def test_colour_kernels_batches_and_odd_heights(gpu, port):
 @pytest.mark.parametrize("o", [1, 2, 3, 4])
 def test_fast_sat_edge_shapes(gpu, port, shape, o):
     """The single-pass fast kernels on awkward shapes: one tile column, fewer rows than the halo, heights that overhang the last
-    tile row, with and without edge records, with and without the gradDot view."""
+    tile row, with and without halo strips, with and without the gradDot view."""
     capi, ctx, torch = gpu
     w, h = shape
     rng = np.random.default_rng(w * 1000 + h * 10 + o)

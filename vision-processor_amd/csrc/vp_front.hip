@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			// halo-strip destinations of this pixel (emit_strip(), hoisted out of the frame loop)
 			const int xm = gx & 63, tb = gx >> 6;
 			const uint32_t so = (uint32_t)strips.o, sh = (uint32_t)strips.h; // VpStrips::rec in 32-bit arithmetic (frame_words * 4 < 2 GiB)
-			const bool se = valid && strips.base && (xm < strips.o || xm >= 64 - strips.o); // this pixel belongs to its tile row's edge record
+			const bool se = valid && strips.base && (xm < strips.o || xm >= 64 - strips.o); // this pixel is one of the first or last o pixels of its tile row
 			const uint32_t voff_se = se ? 4u * (xm < strips.o ? ((uint32_t)tb * sh + (uint32_t)gy) * so + (uint32_t)xm
 			                                                   : ((uint32_t)(strips.tiles_x + tb) * sh + (uint32_t)gy) * so + (uint32_t)(xm - 64) + so) : 0u;
 			const int wcol = g.d0 - cmin;
