@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict_
 //     arithmetic, no divisions in the loop: the register peak of k_sat_fast sat in exactly that code);
 // which brings a workgroup to 24.6 KB of LDS and <= WPC-dependent VGPR budget: WPC = 5 or 6 workgroups per CU.
 // Works for every O in 1..4 (nothing aliases the raw tile).  Same granule protocol, same tile order, same results.
-template<int O, int WPC, bool GD>
+template<int O, int WPC, bool GD, bool RAG>
 __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
 	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
 	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
@@ -762,9 +762,18 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	const int hrow0 = hi0 / O, hk0 = hi0 - hrow0 * O, hrow1 = hi1 / O, hk1 = hi1 - hrow1 * O;              \
 	(void)hrow1; (void)hk1
 	auto clamp_row = [&](int Y0, int row) { return (uint32_t)vp_clampi(Y0 - O + row, 0, h - 1); };
-	auto tile_load = [&](int P, int X0, int Y0, int c4, int r16) {
-		const uint32_t voff = clamp_row(Y0, min(r16 + 16 * P, ROWS - 1)) * row_bytes + 16u * (uint32_t)c4;
-		return __builtin_amdgcn_raw_buffer_load_b128(rs_flat, voff, (uint32_t)X0 * 4u, 2); // aux 2 = nt: read once
+	auto tile_load = [&](int P, int X0, int Y0, int c4, int r16) -> v4u {
+		const uint32_t rowoff = clamp_row(Y0, min(r16 + 16 * P, ROWS - 1)) * row_bytes;
+		if(!RAG || X0 + TW <= w) return (v4u)__builtin_amdgcn_raw_buffer_load_b128(rs_flat, rowoff + 16u * (uint32_t)c4, (uint32_t)X0 * 4u, 2); // aux 2 = nt: read once
+		// the last tile column of a width that is not a multiple of 64 (workgroup-uniform): columns past the image take the edge
+		// pixel, clamp-to-edge as gradientDot.cl:20 reads them
+		v4u v;
+		const int gx = X0 + 4 * c4;
+		v.x = __builtin_amdgcn_raw_buffer_load_b32(rs_flat, rowoff + 4u * (uint32_t)min(gx, w - 1), 0, 0);
+		v.y = __builtin_amdgcn_raw_buffer_load_b32(rs_flat, rowoff + 4u * (uint32_t)min(gx + 1, w - 1), 0, 0);
+		v.z = __builtin_amdgcn_raw_buffer_load_b32(rs_flat, rowoff + 4u * (uint32_t)min(gx + 2, w - 1), 0, 0);
+		v.w = __builtin_amdgcn_raw_buffer_load_b32(rs_flat, rowoff + 4u * (uint32_t)min(gx + 3, w - 1), 0, 0);
+		return v;
 	};
 	// left side: pixels X0 - O + k; right side: X0 + 64 + k (clamp-to-edge at the image border, gradientDot.cl:20)
 	auto halo_load = [&](bool right, int row, int k, int X0, int Y0) -> uint32_t {
@@ -776,6 +785,8 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 			return __builtin_amdgcn_raw_buffer_load_b32(rs_strip, (gy * (uint32_t)O + (uint32_t)k) * 4u, (uint32_t)j * (uint32_t)h * (uint32_t)O * 4u, 0);
 		}
 		if(border) return __builtin_amdgcn_raw_buffer_load_b32(rs_flat, gy * row_bytes, right ? row_bytes - 4u : 0u, 0); // edge column replicated
+		// (the column clamp only acts next to a partial last tile column: its first pixels may already lie past the image)
+		if(RAG) return __builtin_amdgcn_raw_buffer_load_b32(rs_flat, gy * row_bytes + 4u * (uint32_t)min((right ? X0 + TW : X0 - O) + k, w - 1), 0, 0);
 		return __builtin_amdgcn_raw_buffer_load_b32(rs_flat, gy * row_bytes + 4u * (uint32_t)k, (uint32_t)(right ? X0 + TW : X0 - O) * 4u, 0);
 	};
 #define VP2_PREFETCH(X0, Y0)                                           \
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 		}
 
 		// ---- B: local SAT of the lane's 4 x 4 pixels, kept in registers -------------------------------------------------
-		const bool bottom = y0 + TH > h;
+		const bool bottom = y0 + TH > h, ragged = RAG && x0 + TW > w; // RAG: width not a multiple of 64 (host-selected instantiation)
 		int4 sres[4];
 		{
 			int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
@@ -873,10 +884,27 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 				int g1 = grad_dot_pk(hx[5 + O], hx[5 - O], D.y, U.y);
 				int g2 = grad_dot_pk(hx[6 + O], hx[6 - O], D.z, U.z);
 				int g3 = grad_dot_pk(hx[7 + O], hx[7 - O], D.w, U.w);
-				if(bottom) { // only tiles that overhang the image mask rows (workgroup-uniform)
+				if(bottom) { // only tiles that overhang the image mask rows / columns (workgroup-uniform)
 					if(y0 + r >= h) g0 = g1 = g2 = g3 = 0;
 				}
-				if(GD && y0 + r < h) *reinterpret_cast<float4*>(gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
+				if(ragged) {
+					const int gx = x0 + 4 * m;
+					if(gx >= w) g0 = 0;
+					if(gx + 1 >= w) g1 = 0;
+					if(gx + 2 >= w) g2 = 0;
+					if(gx + 3 >= w) g3 = 0;
+				}
+				if(GD && y0 + r < h) {
+					float* gp = gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m;
+					if(!ragged) *reinterpret_cast<float4*>(gp) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
+					else {
+						const int gx = x0 + 4 * m;
+						if(gx < w) gp[0] = (float)g0;
+						if(gx + 1 < w) gp[1] = (float)g1;
+						if(gx + 2 < w) gp[2] = (float)g2;
+						if(gx + 3 < w) gp[3] = (float)g3;
+					}
+				}
 				g1 += g0;
 				g2 += g1;
 				g3 += g2;
@@ -963,7 +991,17 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 				const int r = 16 * wv + 4 * q + it;
 				const int b = Bv[r];
 				const v4i o4 = {sres[it].x + add.x + b, sres[it].y + add.y + b, sres[it].z + add.z + b, sres[it].w + add.w + b};
-				if(y0 + r < h) __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, out_voff + (uint32_t)it * row_bytes, tile_off, 2); // nt: streamed out
+				if(y0 + r < h) {
+					if(!ragged) __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, out_voff + (uint32_t)it * row_bytes, tile_off, 2); // nt: streamed out
+					else {
+						const int gx = x0 + 4 * m;
+						const uint32_t vo = out_voff + (uint32_t)it * row_bytes;
+						if(gx < w) __builtin_amdgcn_raw_buffer_store_b32(o4.x, rs_out, vo, tile_off, 2);
+						if(gx + 1 < w) __builtin_amdgcn_raw_buffer_store_b32(o4.y, rs_out, vo + 4u, tile_off, 2);
+						if(gx + 2 < w) __builtin_amdgcn_raw_buffer_store_b32(o4.z, rs_out, vo + 8u, tile_off, 2);
+						if(gx + 3 < w) __builtin_amdgcn_raw_buffer_store_b32(o4.w, rs_out, vo + 12u, tile_off, 2);
+					}
+				}
 			}
 		}
 		if(!more) break;
@@ -1076,8 +1114,10 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	const int perFrame = a.tilesX * a.tilesY;
 	// k_sat_fast2 keeps VP_SAT_WPC (5 or 6) workgroups per CU resident, k_sat_fast 4
 	const int v2_wpc = getenv("VP_SAT_WPC") ? atoi(getenv("VP_SAT_WPC")) : 5;
-	const bool fast_ok = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
+	// k_sat_fast2 takes any width (the last tile column clamps / masks per pixel); rows need not be 16-byte aligned for buffer accesses
+	const bool aligned16 = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
 			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0);
+	const bool fast_ok = fused && o >= 1 && o <= 4 && ((w % TW) == 0 ? aligned16 : true);
 	const bool v2 = fast_ok && !(getenv("VP_SAT_V2") && atoi(getenv("VP_SAT_V2")) == 0) && !getenv("VP_SAT_DEBUG") && (size_t)w * h * 4 < 0x7fffffffu &&
 			(size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu && (v2_wpc >= 2 && v2_wpc <= 8);
 	int P = ((v2 ? v2_wpc : 4) * ctx->cu_count + batch - 1) / batch;
@@ -1093,9 +1133,12 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
 #define VP_FAST2(OO) \
 		do { \
-			if(graddot_out) k_sat_fast2<OO, 5, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
-			else if(v2_wpc == 6) k_sat_fast2<OO, 6, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
-			else k_sat_fast2<OO, 5, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			if((w % TW) != 0) { \
+				if(graddot_out) k_sat_fast2<OO, 5, true, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+				else k_sat_fast2<OO, 5, false, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			} else if(graddot_out) k_sat_fast2<OO, 5, true, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else if(v2_wpc == 6) k_sat_fast2<OO, 6, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else k_sat_fast2<OO, 5, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 		} while(0)
 		if(o == 1) VP_FAST2(1);
 		else if(o == 2) VP_FAST2(2);
