@@ -18,7 +18,7 @@ def run(N=10):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(N):
-        ctx.resample_raw_mapped(raw, cfg.layout, cfg.qw, cfg.qh, d_map, 1, cfg.fw, cfg.fh, B, flat)
+        ctx.resample_raw_mapped(raw, cfg.layout, cfg.qw, cfg.qh, d_map, int(os.environ.get("VP_MODE", "1")), cfg.fw, cfg.fh, B, flat)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / N * 1000
 for rnd in range(6):

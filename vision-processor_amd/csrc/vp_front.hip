@@ -391,7 +391,8 @@ __device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
 
 // Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
 // sample directly (bayer4_eval); results are identical either way.
-template<int LAYOUT, bool FLT>
+// VARIANT 0: BILINEAR_RTZ, box staged as bytes; 1: BILINEAR_RTZ, box staged as floats (default); 2: NEAREST, box staged as bytes.
+template<int LAYOUT, int VARIANT>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
 	__shared__ uint32_t stage[RESAMPLE_FPT][STAGE_DW];
@@ -406,11 +407,21 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 	const size_t npx = (size_t)fw * fh;
 	const uint32_t rowb = 2u * (uint32_t)qw;
 	{
-		const Bayer4Stage g = bayer4_stage(px, py, qw, qh);
+		constexpr bool FLT = VARIANT == 1, NEAR = VARIANT == 2;
+		Bayer4Stage g = {};
+		// NEAREST (spec 8.2: texel = floor(u), clamp-to-edge): one texel per positional channel -- even row e / odd row o of the
+		// sensor, even byte column ca / odd byte column cb (resampling.cl:64-79 with the +-0.25 offsets)
+		int nca = 0, ncb = 0, ne = 0, no = 0;
+		if(NEAR) {
+			nca = 2 * vp_clampi((int)floorf(px + 0.25f), 0, qw - 1);
+			ncb = 2 * vp_clampi((int)floorf(px - 0.25f), 0, qw - 1) + 1;
+			ne = 2 * vp_clampi((int)floorf(py + 0.25f), 0, qh - 1);
+			no = 2 * vp_clampi((int)floorf(py - 0.25f), 0, qh - 1) + 1;
+		} else g = bayer4_stage(px, py, qw, qh);
 		// bounding box of this workgroup's windows: dword columns [cmin, cmax), sensor rows [rmin, rmax]
 		// (both fit 16 bits: checked by the host; one packed 16-bit min and max reduction over the workgroup, DPP within a wave)
-		const uint32_t lo_w = wave_reduce_pk16<false>((uint32_t)g.d0 | ((uint32_t)min(g.re0, g.ro0) << 16));
-		const uint32_t hi_w = wave_reduce_pk16<true>((uint32_t)(g.d0 + 2) | ((uint32_t)max(g.re1, g.ro1) << 16));
+		const uint32_t lo_w = wave_reduce_pk16<false>(NEAR ? (uint32_t)(min(nca, ncb) >> 2) | ((uint32_t)min(ne, no) << 16) : (uint32_t)g.d0 | ((uint32_t)min(g.re0, g.ro0) << 16));
+		const uint32_t hi_w = wave_reduce_pk16<true>(NEAR ? (uint32_t)((max(nca, ncb) >> 2) + 1) | ((uint32_t)max(ne, no) << 16) : (uint32_t)(g.d0 + 2) | ((uint32_t)max(g.re1, g.ro1) << 16));
 		const int tid = threadIdx.y * 64 + threadIdx.x;
 		if(threadIdx.x == 0) {
 			red[threadIdx.y][0] = lo_w;
@@ -525,15 +536,52 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					__syncthreads(); // frame j+1 is staged; everybody is done reading frame j's buffer before frame j+2 overwrites it
 				}
 			};
-			if(FLT) run_flt();
+			// NEAREST: the boxes of all frames up front (as `run`), then four byte picks per pixel and frame
+			auto run_near = [&]() {
+				const int own = tid < ndw ? tid : 0, orow = (int)(((float)own + 0.5f) * inv_wdw), ocol = own - orow * wdw;
+				const uint32_t goff = (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol);
+				uint32_t pre[RESAMPLE_FPT];
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff, (uint32_t)min(j, nf - 1) * fb_raw, 0);
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) stage[j][tid] = pre[j];
+				__syncthreads();
+				const int iea = (ne - rmin) * wdw + (nca >> 2) - cmin, ieb = (ne - rmin) * wdw + (ncb >> 2) - cmin;
+				const int ioa = (no - rmin) * wdw + (nca >> 2) - cmin, iob = (no - rmin) * wdw + (ncb >> 2) - cmin;
+				const uint32_t sa = (uint32_t)(nca & 3) * 8u, sb = (uint32_t)(ncb & 3) * 8u;
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) {
+					if(j >= nf) break;
+					const uint32_t* st = stage[j];
+					const uint32_t tea = (st[iea] >> sa) & 0xFF, teb = (st[ieb] >> sb) & 0xFF, toa = (st[ioa] >> sa) & 0xFF, tob = (st[iob] >> sb) & 0xFF;
+					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(tea, teb / 2 + toa / 2, tob) : drgb_pack(teb, tea / 2 + tob / 2, toa);
+					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
+					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
+				}
+			};
+			if(NEAR) run_near();
+			else if(FLT) run_flt();
 			else if(ndw <= 256) run(std::integral_constant<int, 1>());
 			else run(std::integral_constant<int, STAGE_DW / 256>());
 			return;
 		}
 	}
 	if(!valid) return;
-	const Bayer4Geom gd = bayer4_geom(px, py, qw, qh);
 	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)gy * fw + gx;
+	if(VARIANT == 2) {
+		for(int f = f0; f < f1; f++) {
+			Src sr;
+			sr.raw = raw + (size_t)f * src_frame_bytes;
+			sr.p[0] = sr.p[1] = sr.p[2] = sr.p[3] = nullptr;
+			const uint32_t a0 = sample<LAYOUT, VP_SAMPLER_NEAREST, true>(sr, 0, px + 0.25f, py + 0.25f, qw, qh), a1 = sample<LAYOUT, VP_SAMPLER_NEAREST, true>(sr, 1, px - 0.25f, py + 0.25f, qw, qh);
+			const uint32_t a2 = sample<LAYOUT, VP_SAMPLER_NEAREST, true>(sr, 2, px + 0.25f, py - 0.25f, qw, qh), a3 = sample<LAYOUT, VP_SAMPLER_NEAREST, true>(sr, 3, px - 0.25f, py - 0.25f, qw, qh);
+			const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(a0, a1 / 2 + a2 / 2, a3) : drgb_pack(a1, a0 / 2 + a3 / 2, a2);
+			out[(size_t)f * npx] = px4;
+			emit_strip(strips, f, gx, gy, px4);
+		}
+		return;
+	}
+	const Bayer4Geom gd = bayer4_geom(px, py, qw, qh);
 	for(int f = f0; f < f1; f++) {
 		uint32_t p[4];
 		bayer4_eval(raw + (size_t)f * src_frame_bytes, gd, p);
@@ -639,17 +687,22 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	const float2* m2 = reinterpret_cast<const float2*>(map);
 	// staged kernel: Bayer + BILINEAR_RTZ with dword-aligned sensor rows; a frame group's spans must fit the 32-bit buffer offsets
 	const size_t span = (size_t)RESAMPLE_FPT * std::max(std::max(frame_bytes, (size_t)fw * fh * 4), strips.base ? strips.frame_words * 4 : (size_t)0);
-	if(layout != VP_LAYOUT_BGR && sampler_mode == VP_SAMPLER_BILINEAR_RTZ && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
+	if(layout != VP_LAYOUT_BGR && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
 			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
 		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
 		const bool flt = !(getenv("VP_RS_FLT") && atoi(getenv("VP_RS_FLT")) == 0); // float-staged variant (default; VP_RS_FLT=0 selects the byte-staged one for A/B)
+		const int variant = sampler_mode == VP_SAMPLER_NEAREST ? 2 : (flt ? 1 : 0);
+#define VP_RST(L, V) k_resample_staged<L, V><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch)
 		if(layout == VP_LAYOUT_RGGB) {
-			if(flt) k_resample_staged<VP_LAYOUT_RGGB, true><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
-			else k_resample_staged<VP_LAYOUT_RGGB, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+			if(variant == 2) VP_RST(VP_LAYOUT_RGGB, 2);
+			else if(variant == 1) VP_RST(VP_LAYOUT_RGGB, 1);
+			else VP_RST(VP_LAYOUT_RGGB, 0);
 		} else {
-			if(flt) k_resample_staged<VP_LAYOUT_GRBG, true><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
-			else k_resample_staged<VP_LAYOUT_GRBG, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+			if(variant == 2) VP_RST(VP_LAYOUT_GRBG, 2);
+			else if(variant == 1) VP_RST(VP_LAYOUT_GRBG, 1);
+			else VP_RST(VP_LAYOUT_GRBG, 0);
 		}
+#undef VP_RST
 		return vp_launch_ok("raw2quad+resampling (staged)");
 	}
 #define VP_RM(L, M) k_resample_mapped<L, M><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch)
