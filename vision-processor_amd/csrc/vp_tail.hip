@@ -345,12 +345,9 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 		// clamped centre, in Bx coordinates (origin x0-1-r, y0-1-r)
 		const int cx = vp_clampi(x0 - 1 + bxx, 0, w - 1) - (x0 - 1 - r), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - 1 - r);
 		const int32_t* c = bx + cy * BXW + cx;
-		const float pp = (float)c[BXW + 1];
-		const float nn = (float)c[-r * BXW - r];
-		const float pn = (float)(-c[-r * BXW + 1]);
-		const float np = (float)(-c[BXW - r]);
-		const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
-		const float m = b < a ? b : a;
+		// min(min(pp, nn), min(pn, np)) of satBlobCenter.cl:41 taken on the exact int32 box sums and converted once: int -> float
+		// conversion is monotonic, so the converted minimum equals the minimum of the converted values
+		const float m = (float)min(min(c[BXW + 1], c[-r * BXW - r]), min(-c[-r * BXW + 1], -c[BXW - r]));
 		if(RT >= 3 && RT <= 10) {
 			// m / (r*r), correctly rounded, without the division sequence: q0 = m*rcp, e = fma(-d, q0, m), q = fma(e, rcp, q0).
 			// Exhaustively verified equal to m / d for every float m = (float)n, |n| <= 2^27, d = 9 .. 100 (tools/divcheck.hip);
@@ -369,16 +366,8 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 			const int2 ppi = *reinterpret_cast<const int2*>(c + BXW + 1), nni = *reinterpret_cast<const int2*>(c - r * BXW - r);
 			const int2 pni = *reinterpret_cast<const int2*>(c - r * BXW + 1), npi = *reinterpret_cast<const int2*>(c + BXW - r);
 			float2 o;
-			{
-				const float pp = (float)ppi.x, nn = (float)nni.x, pn = (float)(-pni.x), np = (float)(-npi.x);
-				const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
-				o.x = quot(b < a ? b : a);
-			}
-			{
-				const float pp = (float)ppi.y, nn = (float)nni.y, pn = (float)(-pni.y), np = (float)(-npi.y);
-				const float a = nn < pp ? nn : pp, b = np < pn ? np : pn;
-				o.y = quot(b < a ? b : a);
-			}
+			o.x = quot((float)min(min(ppi.x, nni.x), min(-pni.x, -npi.x))); // integer minimum, one conversion (see bc_entry)
+			o.y = quot((float)min(min(ppi.y, nni.y), min(-pni.y, -npi.y)));
 			*reinterpret_cast<float2*>(bc + by * BW + bxx) = o;
 		};
 		static_assert(!PAIRS || (RT >= 3 && RT <= 10), "the fma quotient is verified for r = 3 .. 10 only");
