@@ -591,6 +591,116 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 	}
 }
 
+// BGR8 sensor (OpenCV driver layout, resampling.cl:56-61: the three channels are sampled at the same position): the staged
+// kernel for interleaved 3-byte pixels.  Same plan as k_resample_staged: workgroup bounding box of the footprints, the boxes of
+// all frames of the group requested up front, BILINEAR_RTZ staged as floats one frame at a time (every byte converted once by
+// the thread that fetched it), NEAREST staged as bytes.  Needs 3 * qw % 4 == 0 (dword-aligned sensor rows).
+template<int MODE>
+__global__ __launch_bounds__(256) void k_resample_staged_bgr(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
+		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
+	__shared__ uint32_t stage[RESAMPLE_FPT][STAGE_DW];
+	__shared__ uint32_t red[4][2];
+	constexpr bool NEAR = MODE == VP_SAMPLER_NEAREST;
+	const unsigned bz = blockIdx.z;
+	const int gx = (int)blockIdx.x * 64 + threadIdx.x;
+	const int gy = (int)blockIdx.y * 4 + threadIdx.y;
+	const bool valid = gx < fw && gy < fh;
+	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
+	const float px = pos.x, py = pos.y;
+	const int f0 = (int)bz * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT), nf = f1 - f0;
+	const size_t npx = (size_t)fw * fh;
+	const uint32_t rowb = 3u * (uint32_t)qw;
+	// footprint: pixel columns i0, i1 and rows j0, j1 (NEAREST: i1 = i0 = floor(u), j likewise)
+	Axis ax, ay;
+	if(NEAR) {
+		ax.i0 = ax.i1 = vp_clampi((int)floorf(px), 0, qw - 1);
+		ay.i0 = ay.i1 = vp_clampi((int)floorf(py), 0, qh - 1);
+		ax.a = ay.a = 0.0f;
+	} else {
+		ax = axis_lin(px, qw);
+		ay = axis_lin(py, qh);
+	}
+	const uint32_t lo_w = wave_reduce_pk16<false>((uint32_t)((3 * ax.i0) >> 2) | ((uint32_t)ay.i0 << 16));
+	const uint32_t hi_w = wave_reduce_pk16<true>((uint32_t)(((3 * ax.i1 + 2) >> 2) + 1) | ((uint32_t)ay.i1 << 16));
+	const int tid = threadIdx.y * 64 + threadIdx.x;
+	if(threadIdx.x == 0) {
+		red[threadIdx.y][0] = lo_w;
+		red[threadIdx.y][1] = hi_w;
+	}
+	__syncthreads();
+	const uint32_t lo = pk16_min(pk16_min(red[0][0], red[1][0]), pk16_min(red[2][0], red[3][0]));
+	const uint32_t hi = pk16_max(pk16_max(red[0][1], red[1][1]), pk16_max(red[2][1], red[3][1]));
+	const int cmin = (int)(lo & 0xFFFF), rmin = (int)(lo >> 16), cmax = (int)(hi & 0xFFFF), rmax = (int)(hi >> 16);
+	const int wdw = cmax - cmin, hr = rmax - rmin + 1, ndw = wdw * hr;
+	uint32_t* outp = reinterpret_cast<uint32_t*>(flat) + (size_t)min(gy, fh - 1) * fw + min(gx, fw - 1);
+	if(ndw <= STAGE_DW) { // workgroup-uniform
+		const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)f0 * src_frame_bytes, 0, (int)((size_t)nf * src_frame_bytes), 0x00020000);
+		const float inv_wdw = __builtin_amdgcn_rcpf((float)wdw);
+		const int own = tid < ndw ? tid : 0, orow = (int)(((float)own + 0.5f) * inv_wdw), ocol = own - orow * wdw;
+		const uint32_t goff = (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol);
+		uint32_t pre[RESAMPLE_FPT];
+#pragma unroll
+		for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff, (uint32_t)min(j, nf - 1) * (uint32_t)src_frame_bytes, 0);
+		// byte index (within a box row) of channel 0 of the two footprint columns
+		const int b0 = 3 * ax.i0 - 4 * cmin, b1 = 3 * ax.i1 - 4 * cmin;
+		if(NEAR) {
+#pragma unroll
+			for(int j = 0; j < RESAMPLE_FPT; j++) stage[j][tid] = pre[j];
+			__syncthreads();
+			const int bi = (ay.i0 - rmin) * 4 * wdw + b0;
+#pragma unroll
+			for(int j = 0; j < RESAMPLE_FPT; j++) {
+				if(j >= nf) break;
+				const uint8_t* sb = reinterpret_cast<const uint8_t*>(stage[j]) + bi;
+				const uint32_t px4 = drgb_pack(sb[2], sb[1], sb[0]); // resampling.cl:56-61: r = channel 2, g = 1, b = 0
+				if(valid) {
+					outp[(size_t)(f0 + j) * npx] = px4;
+					emit_strip(strips, f0 + j, gx, gy, px4);
+				}
+			}
+		} else {
+			float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][1024]: one float per staged byte
+			const int RP = 4 * wdw;
+			float* wq = F + orow * RP + 4 * ocol;
+			auto put = [&](int buf, uint32_t v) {
+				if(tid < ndw) *reinterpret_cast<float4*>(wq + buf * 1024) = make_float4((float)(v & 0xFF), (float)((v >> 8) & 0xFF), (float)((v >> 16) & 0xFF), (float)(v >> 24));
+			};
+			const float* t00 = F + (ay.i0 - rmin) * RP + b0;
+			const float* t10 = F + (ay.i0 - rmin) * RP + b1;
+			const float* t01 = F + (ay.i1 - rmin) * RP + b0;
+			const float* t11 = F + (ay.i1 - rmin) * RP + b1;
+			put(0, pre[0]);
+			__syncthreads();
+#pragma unroll
+			for(int j = 0; j < RESAMPLE_FPT; j++) {
+				if(j >= nf) break;
+				const int o = (j & 1) * 1024;
+				const uint32_t cb = bilin(t00[o], t10[o], t01[o], t11[o], ax.a, ay.a);
+				const uint32_t cg = bilin(t00[o + 1], t10[o + 1], t01[o + 1], t11[o + 1], ax.a, ay.a);
+				const uint32_t cr = bilin(t00[o + 2], t10[o + 2], t01[o + 2], t11[o + 2], ax.a, ay.a);
+				if(j + 1 < nf) put((j + 1) & 1, pre[j + 1 < RESAMPLE_FPT ? j + 1 : j]);
+				const uint32_t px4 = drgb_pack(cr, cg, cb);
+				if(valid) {
+					outp[(size_t)(f0 + j) * npx] = px4;
+					emit_strip(strips, f0 + j, gx, gy, px4);
+				}
+				__syncthreads();
+			}
+		}
+		return;
+	}
+	if(!valid) return;
+	for(int f = f0; f < f1; f++) { // box too large for the stage: sample directly
+		Src sr;
+		sr.raw = raw + (size_t)f * src_frame_bytes;
+		sr.p[0] = sr.p[1] = sr.p[2] = sr.p[3] = nullptr;
+		const uint32_t r = sample<VP_LAYOUT_BGR, MODE, true>(sr, 2, px, py, qw, qh), g = sample<VP_LAYOUT_BGR, MODE, true>(sr, 1, px, py, qw, qh), b = sample<VP_LAYOUT_BGR, MODE, true>(sr, 0, px, py, qw, qh);
+		const uint32_t px4 = drgb_pack(r, g, b);
+		outp[(size_t)f * npx] = px4;
+		emit_strip(strips, f, gx, gy, px4);
+	}
+}
+
 template<int LAYOUT, int MODE>
 __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
@@ -687,6 +797,13 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	const float2* m2 = reinterpret_cast<const float2*>(map);
 	// staged kernel: Bayer + BILINEAR_RTZ with dword-aligned sensor rows; a frame group's spans must fit the 32-bit buffer offsets
 	const size_t span = (size_t)RESAMPLE_FPT * std::max(std::max(frame_bytes, (size_t)fw * fh * 4), strips.base ? strips.frame_words * 4 : (size_t)0);
+	if(layout == VP_LAYOUT_BGR && (qw & 3) == 0 && batch >= 2 && (size_t)RESAMPLE_FPT * frame_bytes < 0x7fffffffu && (reinterpret_cast<uintptr_t>(raw) & 3) == 0 &&
+			qw < 21845 && qh < 65536 && vp_div_up(fh, 4) <= 65535 && !(getenv("VP_RS_BGR") && atoi(getenv("VP_RS_BGR")) == 0)) {
+		const dim3 grid3(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
+		if(sampler_mode == VP_SAMPLER_NEAREST) k_resample_staged_bgr<VP_SAMPLER_NEAREST><<<grid3, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		else k_resample_staged_bgr<VP_SAMPLER_BILINEAR_RTZ><<<grid3, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch);
+		return vp_launch_ok("raw2quad+resampling (staged, BGR)");
+	}
 	if(layout != VP_LAYOUT_BGR && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
 			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
 		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
