@@ -49,6 +49,7 @@ struct TiledArgs {
 	int* host_flag; // pinned, device-mapped
 	VpStrips strips; // optional halo strips (base == nullptr: halo columns are read from flat)
 	int debug;      // timing experiments only (VP_SAT_DEBUG env): bit0 = skip look-back waits (WRONG results)
+	int single;     // k_sat_fast2: as many workgroups as tiles per frame -- each takes ONE ticket and none in advance
 };
 
 __device__ __forceinline__ u64 ld_granule(const u64* p) {
@@ -731,7 +732,9 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	uint32_t pending = 0;
 	if(loader) {
 		const uint32_t t0 = atomicAdd(queue, 1u);
-		pending = atomicAdd(queue, 1u);
+		// (with one workgroup per tile a second ticket could only be out of range: not asking for it halves the burst on the
+		// frame's ticket counter, which is what a single-frame launch spends a third of its time on)
+		pending = a.single ? a.ticket_base + (uint32_t)perFrame : atomicAdd(queue, 1u);
 		misc[0] = (int)(t0 - a.ticket_base);
 	}
 	__syncthreads();
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 		VP2_COMMIT_ALL();
 		if(loader) misc[3] = (int)(pending - a.ticket_base);
 		lds_barrier();
-		if(loader) pending = atomicAdd(queue, 1u);
+		if(loader && !a.single) pending = atomicAdd(queue, 1u);
 		const int next = misc[3];
 		const bool more = next >= 0 && next < perFrame;
 
@@ -1123,7 +1126,8 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	int P = ((v2 ? v2_wpc : 4) * ctx->cu_count + batch - 1) / batch;
 	if(P < 1) P = 1;
 	if(P > perFrame) P = perFrame;
-	ctx->sat_ticket_base[stream] += (uint32_t)(perFrame + 2 * P);
+	a.single = v2 && P >= perFrame ? 1 : 0;
+	ctx->sat_ticket_base[stream] += a.single ? (uint32_t)P : (uint32_t)(perFrame + 2 * P);
 	const unsigned grid = (unsigned)P * (unsigned)batch;
 	const bool pipe = fused && o >= 1 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !(a.debug & 2);
 	const bool fast = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
