@@ -103,6 +103,30 @@ int vp_copy_d2h(VpContext* ctx, int stream, void* dst_h, const void* src_d, size
 int vp_copy_d2h_sync(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes);
 int vp_memset_device(VpContext* ctx, int stream, void* dst_d, int value, size_t bytes);
 
+/* ---- buffer and image objects: what CLArray / RawImage and CLImage are made of ---------------------------------------------------
+ * VpBuffer = CLArray (opencl.h:154-165, opencl.cpp:146-147): a device buffer; `init` non-NULL copies host data in at creation
+ * (the CL_MEM_COPY_HOST_PTR constructor).  map / unmap are the blocking CLMap of opencl.h:115-152: map(read_back) returns a pinned
+ * host shadow holding the device contents (or just waits for the stream when read_back = 0), unmap(write_back) copies it back.
+ * VpImage = CLImage from the pool of OpenCL::acquire (opencl.cpp:108-122): an idle image of the same format and size is handed
+ * out again, otherwise one is allocated; release returns it to the pool (the reference does that when the last shared_ptr copy
+ * goes away); the pool never frees before vp_ctx_destroy.  Rows are tightly packed; VP_FMT_NV12 allocates 2 bytes per pixel like
+ * the reference (opencl.cpp:27). */
+typedef struct VpBuffer VpBuffer;
+typedef struct VpImage VpImage;
+typedef enum { VP_FMT_RGBA8 = 0, VP_FMT_U8 = 1, VP_FMT_F32 = 2, VP_FMT_NV12 = 3 } VpPixelFormat;
+int vp_buffer_create(VpContext* ctx, size_t bytes, const void* init, VpBuffer** out);
+void* vp_buffer_device(const VpBuffer* buffer);
+size_t vp_buffer_size(const VpBuffer* buffer);
+int vp_buffer_map(VpContext* ctx, int stream, VpBuffer* buffer, int read_back, void** host);
+int vp_buffer_unmap(VpContext* ctx, int stream, VpBuffer* buffer, int write_back);
+int vp_buffer_destroy(VpContext* ctx, VpBuffer* buffer);
+int vp_image_acquire(VpContext* ctx, int format, int w, int h, VpImage** out);
+int vp_image_release(VpContext* ctx, VpImage* image);
+void* vp_image_device(const VpImage* image);
+int vp_image_info(const VpImage* image, int* format, int* w, int* h, size_t* bytes);
+int vp_image_map(VpContext* ctx, int stream, VpImage* image, int read_back, void** host);
+int vp_image_unmap(VpContext* ctx, int stream, VpImage* image, int write_back);
+
 /* ---- stage kernels ------------------------------------------------------------------------------------------------ */
 
 /* raw2quad (raw2quad.cl:21-39; launched by Resources::raw2quad, Resources.cpp:138-143).

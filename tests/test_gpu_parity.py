@@ -346,6 +346,56 @@ def test_fast_sat_edge_shapes(gpu, port, shape, o):
                 assert np.array_equal(host(d_gd[i]), want_gd[i])
 
 
+def test_abi_buffer_and_image_objects(gpu):
+    """VpBuffer / VpImage (the objects behind CLArray and the CLImage pool): blocking map / unmap round trips, initial contents,
+    and the pool semantics of OpenCL::acquire (opencl.cpp:108-122): an idle image of the same format and size is handed out again."""
+    import ctypes as C
+    capi, ctx, torch = gpu
+    lib = capi.lib()
+    lib.vp_buffer_device.restype = C.c_void_p
+    lib.vp_image_device.restype = C.c_void_p
+    lib.vp_buffer_size.restype = C.c_size_t
+    h = ctx.h
+    data = np.arange(1000, dtype=np.uint8)
+    buf = C.c_void_p()
+    assert lib.vp_buffer_create(h, C.c_size_t(1000), data.ctypes.data_as(C.c_void_p), C.byref(buf)) == 0
+    assert lib.vp_buffer_size(buf) == 1000
+    hp = C.c_void_p()
+    assert lib.vp_buffer_map(h, 0, buf, 1, C.byref(hp)) == 0  # read back the initial contents
+    view = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(1000,))
+    assert np.array_equal(view, data)
+    view[:] = 255 - view
+    assert lib.vp_buffer_unmap(h, 0, buf, 1) == 0             # write back
+    dev = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    assert lib.vp_copy_d2h_sync(h, 0, hp, C.c_void_p(lib.vp_buffer_device(buf)), C.c_size_t(1000)) == 0
+    assert np.array_equal(np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(1000,)), 255 - data)
+    assert lib.vp_buffer_destroy(h, buf) == 0
+    del dev
+    # image pool
+    a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.vp_image_acquire(h, 2, 64, 48, C.byref(a)) == 0   # VP_FMT_F32
+    assert lib.vp_image_acquire(h, 2, 64, 48, C.byref(b)) == 0
+    assert a.value != b.value and lib.vp_image_device(a) != lib.vp_image_device(b)
+    fmt, w, hh, nb = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    assert lib.vp_image_info(a, C.byref(fmt), C.byref(w), C.byref(hh), C.byref(nb)) == 0
+    assert (fmt.value, w.value, hh.value, nb.value) == (2, 64, 48, 64 * 48 * 4)
+    assert lib.vp_image_release(h, a) == 0
+    assert lib.vp_image_acquire(h, 2, 64, 48, C.byref(c)) == 0 and c.value == a.value  # the idle one comes back
+    d = C.c_void_p()
+    assert lib.vp_image_acquire(h, 1, 64, 48, C.byref(d)) == 0 and d.value not in (a.value, b.value)  # other format: a new image
+    assert lib.vp_image_map(h, 0, c, 0, C.byref(hp)) == 0
+    fv = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(48, 64))
+    fv[:] = np.arange(48 * 64, dtype=np.float32).reshape(48, 64)
+    assert lib.vp_image_unmap(h, 0, c, 1) == 0
+    fv[:] = 0
+    assert lib.vp_image_map(h, 0, c, 1, C.byref(hp)) == 0
+    assert np.array_equal(np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_float)), shape=(48, 64)), np.arange(48 * 64, dtype=np.float32).reshape(48, 64))
+    assert lib.vp_image_unmap(h, 0, c, 0) == 0
+    for im in (b, c, d):
+        assert lib.vp_image_release(h, im) == 0
+    assert lib.vp_image_acquire(h, 7, 4, 4, C.byref(d)) != 0  # unknown format is refused
+
+
 def test_full_size_properties(gpu, port):
     """BASELINE.json configs[1] (2048x1536): properties that do not need a full CPU reference run per frame."""
     capi, ctx, torch = gpu

@@ -24,6 +24,19 @@ struct VpWorkspace {
 	size_t bytes = 0;
 };
 
+// device buffer with a lazily allocated pinned shadow for the blocking map / unmap of opencl.h:115-152
+struct VpBuffer {
+	void* dev = nullptr;
+	void* host = nullptr;
+	size_t bytes = 0;
+};
+// pooled 2-D image (opencl.cpp:108-122): tightly packed rows
+struct VpImage {
+	VpBuffer buf;
+	int format = 0, w = 0, h = 0;
+	bool in_use = false;
+};
+
 struct VpContext {
 	int device = 0;
 	int n_streams = 0;
@@ -40,6 +53,7 @@ struct VpContext {
 	bool events_on = false;
 	std::mutex mu;
 	std::vector<VpEventRec> events;
+	std::vector<VpImage*> image_pool; // every image ever acquired; idle ones are handed out again (the pool never frees)
 };
 
 void vp_set_error(const char* fmt, ...);

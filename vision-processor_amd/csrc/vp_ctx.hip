@@ -91,6 +91,11 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 		(void)hipEventDestroy(e.start);
 		(void)hipEventDestroy(e.stop);
 	}
+	for(VpImage* im : ctx->image_pool) {
+		if(im->buf.dev) (void)hipFree(im->buf.dev);
+		if(im->buf.host) (void)hipHostFree(im->buf.host);
+		delete im;
+	}
 	delete ctx;
 }
 
@@ -210,6 +215,134 @@ extern "C" int vp_free_host(VpContext* ctx, void* hptr) {
 	VP_REQUIRE(ctx, "null context");
 	if(hptr) VP_CHECK_HIP(hipHostFree(hptr));
 	return VP_OK;
+}
+
+// ---- buffer and image objects: CLArray / RawImage / CLImage and their blocking maps (opencl.h:115-262, opencl.cpp:108-159) --------
+static int buffer_alloc(VpContext* ctx, VpBuffer& b, size_t bytes) {
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	b.bytes = bytes;
+	hipError_t e = hipMalloc(&b.dev, bytes ? bytes : 1);
+	if(e != hipSuccess) {
+		vp_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+		return VP_ERR_NOMEM;
+	}
+	return VP_OK;
+}
+static int buffer_map(VpContext* ctx, int stream, VpBuffer& b, int read_back, void** host) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(host, "null pointer");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	if(!b.host) {
+		hipError_t e = hipHostMalloc(&b.host, b.bytes ? b.bytes : 1, hipHostMallocDefault);
+		if(e != hipSuccess) {
+			vp_set_error("hipHostMalloc(%zu) failed: %s", b.bytes, hipGetErrorString(e));
+			return VP_ERR_NOMEM;
+		}
+	}
+	if(read_back) VP_CHECK_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx->streams[stream]));
+	VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream])); // blocking, like clEnqueueMapBuffer(..., CL_TRUE, ...)
+	*host = b.host;
+	return VP_OK;
+}
+static int buffer_unmap(VpContext* ctx, int stream, VpBuffer& b, int write_back) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	if(write_back) {
+		VP_REQUIRE(b.host, "unmap of a buffer that was never mapped");
+		VP_CHECK_HIP(hipMemcpyAsync(b.dev, b.host, b.bytes, hipMemcpyHostToDevice, ctx->streams[stream]));
+		VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
+	}
+	return VP_OK;
+}
+
+extern "C" int vp_buffer_create(VpContext* ctx, size_t bytes, const void* init, VpBuffer** out) {
+	VP_REQUIRE(ctx && out, "bad arguments");
+	VpBuffer* b = new VpBuffer();
+	int rc = buffer_alloc(ctx, *b, bytes);
+	if(rc == VP_OK && init && bytes) { // CL_MEM_COPY_HOST_PTR (opencl.cpp:147)
+		if(hipMemcpy(b->dev, init, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+			vp_set_error("initial copy of %zu bytes failed", bytes);
+			rc = VP_ERR_HIP;
+		}
+	}
+	if(rc != VP_OK) {
+		if(b->dev) (void)hipFree(b->dev);
+		delete b;
+		return rc;
+	}
+	*out = b;
+	return VP_OK;
+}
+extern "C" void* vp_buffer_device(const VpBuffer* b) { return b ? b->dev : nullptr; }
+extern "C" size_t vp_buffer_size(const VpBuffer* b) { return b ? b->bytes : 0; }
+extern "C" int vp_buffer_map(VpContext* ctx, int stream, VpBuffer* b, int read_back, void** host) {
+	VP_REQUIRE(b, "null buffer");
+	return buffer_map(ctx, stream, *b, read_back, host);
+}
+extern "C" int vp_buffer_unmap(VpContext* ctx, int stream, VpBuffer* b, int write_back) {
+	VP_REQUIRE(b, "null buffer");
+	return buffer_unmap(ctx, stream, *b, write_back);
+}
+extern "C" int vp_buffer_destroy(VpContext* ctx, VpBuffer* b) {
+	VP_REQUIRE(ctx, "null context");
+	if(!b) return VP_OK;
+	(void)hipSetDevice(ctx->device);
+	if(b->dev) (void)hipFree(b->dev);
+	if(b->host) (void)hipHostFree(b->host);
+	delete b;
+	return VP_OK;
+}
+
+static size_t pixel_bytes(int format) { // PixelFormat::pixelSize() (opencl.cpp:24-27); NV12 is over-allocated like the reference's
+	return format == VP_FMT_U8 ? 1 : (format == VP_FMT_NV12 ? 2 : 4);
+}
+extern "C" int vp_image_acquire(VpContext* ctx, int format, int w, int h, VpImage** out) {
+	VP_REQUIRE(ctx && out && w > 0 && h > 0 && format >= VP_FMT_RGBA8 && format <= VP_FMT_NV12, "vp_image_acquire: bad arguments");
+	std::lock_guard<std::mutex> g(ctx->mu);
+	for(VpImage* im : ctx->image_pool)
+		if(!im->in_use && im->format == format && im->w == w && im->h == h) {
+			im->in_use = true;
+			*out = im;
+			return VP_OK;
+		}
+	VpImage* im = new VpImage();
+	const int rc = buffer_alloc(ctx, im->buf, (size_t)w * h * pixel_bytes(format));
+	if(rc != VP_OK) {
+		delete im;
+		return rc;
+	}
+	im->format = format;
+	im->w = w;
+	im->h = h;
+	im->in_use = true;
+	ctx->image_pool.push_back(im);
+	*out = im;
+	return VP_OK;
+}
+extern "C" int vp_image_release(VpContext* ctx, VpImage* im) {
+	VP_REQUIRE(ctx, "null context");
+	if(im) {
+		std::lock_guard<std::mutex> g(ctx->mu);
+		im->in_use = false;
+	}
+	return VP_OK;
+}
+extern "C" void* vp_image_device(const VpImage* im) { return im ? im->buf.dev : nullptr; }
+extern "C" int vp_image_info(const VpImage* im, int* format, int* w, int* h, size_t* bytes) {
+	VP_REQUIRE(im, "null image");
+	if(format) *format = im->format;
+	if(w) *w = im->w;
+	if(h) *h = im->h;
+	if(bytes) *bytes = im->buf.bytes;
+	return VP_OK;
+}
+extern "C" int vp_image_map(VpContext* ctx, int stream, VpImage* im, int read_back, void** host) {
+	VP_REQUIRE(im, "null image");
+	return buffer_map(ctx, stream, im->buf, read_back, host);
+}
+extern "C" int vp_image_unmap(VpContext* ctx, int stream, VpImage* im, int write_back) {
+	VP_REQUIRE(im, "null image");
+	return buffer_unmap(ctx, stream, im->buf, write_back);
 }
 
 extern "C" int vp_copy_h2d(VpContext* ctx, int stream, void* dst_d, const void* src_h, size_t bytes) {

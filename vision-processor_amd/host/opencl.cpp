@@ -19,7 +19,6 @@ OpenCL::OpenCL() { // opencl.cpp:34-50: first GPU, one in-order queue with profi
 }
 
 OpenCL::~OpenCL() {
-	pool.clear();
 	nv12pool.clear();
 	if(satTable) vp_free_device(ctx, satTable);
 	vp_ctx_destroy(ctx);
@@ -64,15 +63,7 @@ void OpenCL::printRuntimes() { // opencl.cpp:94-101
 void OpenCL::clearEvents() { VP_OR_FATAL(vp_events_clear(ctx)); }
 
 std::shared_ptr<CLImage> OpenCL::acquire(const PixelFormat* format, int width, int height, const std::string& name) { // opencl.cpp:108-122
-	auto& formatPool = pool[format];
-	for(auto& i : formatPool)
-		if(i.use_count() == 1 && i->width == width && i->height == height) {
-			i->name = name;
-			return i;
-		}
-	auto image = std::make_shared<CLImage>(format, width, height, name);
-	formatPool.push_back(image);
-	return image;
+	return std::make_shared<CLImage>(format, width, height, name); // the pool is vp_image_acquire's: an idle image of this format and size is reused
 }
 
 std::shared_ptr<RawImage> OpenCL::acquireNV12(int width, int height) { // opencl.cpp:124-135
@@ -161,31 +152,23 @@ void OpenCL::dispatch(const cl::Kernel& k, const cl::EnqueueArgs& e, const std::
 }
 
 // ---- memory objects ------------------------------------------------------------------------------------------------------
-static std::shared_ptr<void> deviceAlloc(size_t bytes) {
-	void* p = nullptr;
-	if(vp_malloc_device(OpenCL::context(), bytes, &p) != VP_OK) FATAL("Error during image allocation: " << vp_last_error());
-	return std::shared_ptr<void>(p, [](void* q) { if(OpenCL::context()) vp_free_device(OpenCL::context(), q); });
-}
-static std::shared_ptr<void> hostAlloc(size_t bytes) {
-	void* p = nullptr;
-	if(vp_malloc_host(OpenCL::context(), bytes, &p) != VP_OK) FATAL("Error during image allocation: " << vp_last_error());
-	return std::shared_ptr<void>(p, [](void* q) { if(OpenCL::context()) vp_free_host(OpenCL::context(), q); });
+static std::shared_ptr<VpBuffer> bufferCreate(size_t bytes, const void* init) {
+	VpBuffer* b = nullptr;
+	if(vp_buffer_create(OpenCL::context(), bytes, init, &b) != VP_OK) FATAL("Error during buffer allocation: " << vp_last_error());
+	return std::shared_ptr<VpBuffer>(b, [](VpBuffer* q) { if(OpenCL::context()) vp_buffer_destroy(OpenCL::context(), q); });
 }
 
-CLArray::CLArray(int size): buffer{nullptr}, size(size), device(deviceAlloc((size_t)size)), host(hostAlloc((size_t)size)) { const_cast<cl::Buffer&>(buffer).dptr = device.get(); }
-CLArray::CLArray(void* data, int size): CLArray(size) { // CL_MEM_COPY_HOST_PTR (opencl.cpp:147)
-	memcpy(host.get(), data, (size_t)size);
-	VP_OR_FATAL(vp_copy_h2d(OpenCL::context(), 0, buffer.dptr, host.get(), (size_t)size));
-	VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
+CLArray::CLArray(int size): buffer{nullptr}, size(size), object(bufferCreate((size_t)size, nullptr)) { const_cast<cl::Buffer&>(buffer).dptr = vp_buffer_device(object.get()); }
+CLArray::CLArray(void* data, int size): buffer{nullptr}, size(size), object(bufferCreate((size_t)size, data)) { // CL_MEM_COPY_HOST_PTR (opencl.cpp:147)
+	const_cast<cl::Buffer&>(buffer).dptr = vp_buffer_device(object.get());
 }
 
 CLImage::CLImage(const PixelFormat* format): format(format), width(0), height(0) {}
-CLImage::CLImage(const PixelFormat* format, int width, int height, std::string name): format(format), width(width), height(height), name(std::move(name)), device(deviceAlloc((size_t)width * height * format->pixelSize())) {
-	image.dptr = device.get();
+CLImage::CLImage(const PixelFormat* format, int width, int height, std::string name): format(format), width(width), height(height), name(std::move(name)) {
+	VpImage* im = nullptr;
+	if(vp_image_acquire(OpenCL::context(), format->imageFormat(), width, height, &im) != VP_OK) FATAL("Error during image allocation: " << vp_last_error());
+	pooled = std::shared_ptr<VpImage>(im, [](VpImage* q) { if(OpenCL::context()) vp_image_release(OpenCL::context(), q); });
+	image.dptr = vp_image_device(im);
 	image.width = width;
 	image.height = height;
-}
-void* CLImage::hostShadow() const {
-	if(!host) host = hostAlloc(bytes());
-	return host.get();
 }

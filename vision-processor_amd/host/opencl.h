@@ -66,6 +66,7 @@ public:
 	const int rowStride;
 	const bool color;
 	const int layout; // VpLayout for raw formats, -1 otherwise
+	int imageFormat() const { return this == &U8 ? VP_FMT_U8 : (this == &F32 ? VP_FMT_F32 : (this == &NV12 ? VP_FMT_NV12 : VP_FMT_RGBA8)); }
 	const char* kernelOptions;
 private:
 	PixelFormat(int stride, int rowStride, bool color, int layout, const char* options): stride(stride), rowStride(rowStride), color(color), layout(layout), kernelOptions(options) {}
@@ -122,8 +123,7 @@ private:
 
 	static VpContext* ctx;
 	int samplerMode = VP_SAMPLER_BILINEAR_RTZ, satVariant = VP_SAT_TILED, listOrder = VP_ORDER_RASTER;
-	std::map<const PixelFormat*, std::vector<std::shared_ptr<CLImage>>> pool;
-	std::vector<std::shared_ptr<RawImage>> nv12pool;
+	std::vector<std::shared_ptr<RawImage>> nv12pool; // (the CLImage pool lives behind vp_image_acquire / vp_image_release)
 	// state handed from one launch to the next inside rgba2blobCenter: the reference's satHorizontal/satVertical pair becomes one
 	// fused launch, so gradientDot only records its arguments and satHorizontal is a no-op (see dispatch())
 	struct { void* flat = nullptr; void* graddot = nullptr; int w = 0, h = 0, offset = 0; } pendingGrad;
@@ -134,17 +134,15 @@ private:
 template<typename T>
 class CLMap { // opencl.h:114-152: blocking map in the constructor, blocking unmap in the destructor, move-only
 public:
-	CLMap(void* dptr, void* hptr, int size, bool readBack, bool writeBack): dptr(dptr), map((T*)hptr), size(size), writeBack(writeBack) {
-		if(readBack) VP_OR_FATAL(vp_copy_d2h_sync(OpenCL::context(), 0, hptr, dptr, (size_t)size));
-		else VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
+	CLMap(VpBuffer* buffer, bool readBack, bool writeBack): buffer(buffer), writeBack(writeBack) {
+		void* h = nullptr;
+		VP_OR_FATAL(vp_buffer_map(OpenCL::context(), 0, buffer, readBack, &h));
+		map = (T*)h;
 	}
 	~CLMap() {
-		if(unmoved && writeBack) {
-			VP_OR_FATAL(vp_copy_h2d(OpenCL::context(), 0, dptr, map, (size_t)size));
-			VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
-		}
+		if(unmoved) VP_OR_FATAL(vp_buffer_unmap(OpenCL::context(), 0, buffer, writeBack));
 	}
-	CLMap(CLMap&& other) noexcept: dptr(other.dptr), map(other.map), size(other.size), writeBack(other.writeBack) { other.unmoved = false; }
+	CLMap(CLMap&& other) noexcept: buffer(other.buffer), map(other.map), writeBack(other.writeBack) { other.unmoved = false; }
 	CLMap(const CLMap&) = delete;
 	CLMap& operator=(const CLMap&) = delete;
 	T*& operator*() { return map; }
@@ -153,9 +151,8 @@ public:
 	const T& operator[](int i) const { return map[i]; }
 
 private:
-	void* dptr;
+	VpBuffer* buffer;
 	T* map;
-	int size;
 	bool writeBack;
 	bool unmoved = true;
 };
@@ -165,15 +162,15 @@ public:
 	explicit CLArray(int size);
 	CLArray(void* data, int size);
 
-	template<typename T> CLMap<T> read() const { return CLMap<T>(buffer.dptr, host.get(), size, true, false); }
-	template<typename T> CLMap<T> write() { return CLMap<T>(buffer.dptr, host.get(), size, false, true); }
-	template<typename T> CLMap<T> readWrite() { return CLMap<T>(buffer.dptr, host.get(), size, true, true); }
+	template<typename T> CLMap<T> read() const { return CLMap<T>(object.get(), true, false); }
+	template<typename T> CLMap<T> write() { return CLMap<T>(object.get(), false, true); }
+	template<typename T> CLMap<T> readWrite() { return CLMap<T>(object.get(), true, true); }
 
 	const cl::Buffer buffer;
 	const int size;
 
 private:
-	std::shared_ptr<void> device, host; // released when the last copy of the array goes away
+	std::shared_ptr<VpBuffer> object; // vp_buffer_create / vp_buffer_destroy: released when the last copy of the array goes away
 };
 
 class RawImage: public CLArray { // opencl.h:168-188 -- for Bayer formats width/height count 2x2 cells
@@ -210,30 +207,26 @@ public:
 	std::string name;
 
 	size_t bytes() const { return (size_t)width * height * format->pixelSize(); }
-	void* hostShadow() const;
+	VpImage* object() const { return pooled.get(); }
 
 private:
-	std::shared_ptr<void> device;
-	mutable std::shared_ptr<void> host; // pinned shadow, allocated on the first map
+	std::shared_ptr<VpImage> pooled; // vp_image_acquire; handed back to the pool (vp_image_release) when the last copy goes away
 };
 
 template<typename T>
 class CLImageMap { // opencl.h:215-262 (without the cv::Mat view)
 public:
-	CLImageMap(const CLImage& image, bool readBack, bool writeBack): dptr(image.image.dptr), bytes(image.bytes()), writeBack(writeBack) {
-		map = (T*)image.hostShadow();
+	CLImageMap(const CLImage& image, bool readBack, bool writeBack): object(image.object()), writeBack(writeBack) {
+		void* h = nullptr;
+		VP_OR_FATAL(vp_image_map(OpenCL::context(), 0, object, readBack, &h));
+		map = (T*)h;
 		bytePitch = (size_t)image.width * image.format->pixelSize();
 		rowPitch = bytePitch / sizeof(T);
-		if(readBack) VP_OR_FATAL(vp_copy_d2h_sync(OpenCL::context(), 0, map, dptr, bytes));
-		else VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
 	}
 	~CLImageMap() {
-		if(unmoved && writeBack) {
-			VP_OR_FATAL(vp_copy_h2d(OpenCL::context(), 0, dptr, map, bytes));
-			VP_OR_FATAL(vp_sync(OpenCL::context(), 0));
-		}
+		if(unmoved) VP_OR_FATAL(vp_image_unmap(OpenCL::context(), 0, object, writeBack));
 	}
-	CLImageMap(CLImageMap&& other) noexcept: bytePitch(other.bytePitch), rowPitch(other.rowPitch), dptr(other.dptr), map(other.map), bytes(other.bytes), writeBack(other.writeBack) { other.unmoved = false; }
+	CLImageMap(CLImageMap&& other) noexcept: bytePitch(other.bytePitch), rowPitch(other.rowPitch), object(other.object), map(other.map), writeBack(other.writeBack) { other.unmoved = false; }
 	CLImageMap(const CLImageMap&) = delete;
 	CLImageMap& operator=(const CLImageMap&) = delete;
 	T*& operator*() { return map; }
@@ -247,9 +240,8 @@ public:
 	size_t rowPitch;
 
 private:
-	void* dptr;
+	VpImage* object;
 	T* map;
-	size_t bytes;
 	bool writeBack;
 	bool unmoved = true;
 };
