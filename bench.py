@@ -53,6 +53,26 @@ def host_cores():
     return n
 
 
+def opencl_cpu_devices():
+    """report whether a CPU OpenCL device (e.g. PoCL) exists on this box; nothing depends on one."""
+    import ctypes as C
+    try:
+        cl = C.CDLL("libOpenCL.so.1")
+    except OSError:
+        return "no OpenCL ICD loader on this box"
+    n = C.c_uint(0)
+    if cl.clGetPlatformIDs(0, None, C.byref(n)) != 0 or n.value == 0:
+        return "OpenCL loader present, 0 platforms"
+    plats = (C.c_void_p * n.value)()
+    cl.clGetPlatformIDs(n, plats, None)
+    cpus = 0
+    for p in plats:
+        m = C.c_uint(0)
+        if cl.clGetDeviceIDs(C.c_void_p(p), C.c_ulong(2), 0, None, C.byref(m)) == 0:  # CL_DEVICE_TYPE_CPU
+            cpus += m.value
+    return f"{n.value} OpenCL platform(s), {cpus} CPU device(s)" + ("" if cpus else ": the reference's own OpenCL path cannot run here")
+
+
 def cpu_baseline(cfg, seconds):
     """The oracle is used here only as the timed CPU baseline (kind 'port'), never as part of the measured GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -74,7 +94,7 @@ def cpu_baseline(cfg, seconds):
         one(n)
         n += 1
     dt = time.perf_counter() - t0
-    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "opencl_cpu_runtime": opencl_cpu_devices(),
            "sample": f"{n} frames of {cfg.name} through oracle/vp_oracle.c vpo_frame (fp32 sequential SAT, rows sharded over {cores} pthreads), {dt:.1f} s"}
     # For information: the reference's own kernel/*.cl compiled for x86 (oracle/_ref, prebuilt in the build container and carried
     # along), run the way a CPU OpenCL device would run one work-item at a time -- sequential NDRange, one core, two frames.
