@@ -8,11 +8,12 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # strict IEEE binary32: no contraction, no fast-math
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Wall -Wno-unused-function
-CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -Wall -pthread
+# host side: strict IEEE binary32 as well (the hypothesis stage is float arithmetic whose order is part of the restatement)
+CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -Wall -pthread -ffp-contract=off -fno-fast-math
 
 HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
 HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) include/vp_hip.h
-HOST_SRCS := $(PKG)/host/synth.cpp $(PKG)/host/geometry.cpp
+HOST_SRCS := $(PKG)/host/synth.cpp $(PKG)/host/geometry.cpp $(wildcard $(PKG)/host/blobs/*.cpp)
 FACADE_SRCS := $(PKG)/host/frame_loop.cpp $(PKG)/host/Resources.cpp $(PKG)/host/opencl.cpp
 
 .PHONY: all hip host oracle facade clean
@@ -23,7 +24,7 @@ $(PKG)/libvp_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
 
 host: $(PKG)/libvp_host.so
-$(PKG)/libvp_host.so: $(HOST_SRCS) include/vp_hip.h $(wildcard $(PKG)/host/*.h)
+$(PKG)/libvp_host.so: $(HOST_SRCS) include/vp_hip.h include/vp_host.h $(wildcard $(PKG)/host/*.h) $(wildcard $(PKG)/host/blobs/*.h)
 	g++ $(CXXFLAGS) -shared -o $@ $(HOST_SRCS)
 
 ifneq ($(wildcard $(PKG)/host/frame_loop.cpp),)

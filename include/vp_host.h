@@ -1,0 +1,107 @@
+/* vp_host.h -- C ABI of the CPU stage that consumes the GPU hot path's blob list (libvp_host.so; no GPU, no HIP).
+ *
+ * blob list -> robot / ball hypotheses -> SSL_DetectionFrame -> SSL_WrapperPacket bytes.
+ * Each entry names the reference code it replaces (paths relative to the reference tree).  The C++ implementation with the
+ * reference's own function names lives in vision-processor_amd/host/blobs/detection.h; this header is the flat binding a
+ * non-C++ caller (the ctypes tests, a cgo / JNI stub) would use.  Parity of this stage is UNPINNED (see detection.h).
+ */
+#ifndef VP_HOST_H
+#define VP_HOST_H
+
+#include <stdint.h>
+
+#include "vp_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct VphDetector VphDetector; /* the stage's slice of `Resources` + the last SSL_DetectionFrame it produced / decoded */
+
+/* src/blobs/match.h:22-30 -- position in field mm (after Perspective::flat2field), colours widened to int */
+typedef struct VphMatch {
+	float x, y;
+	int32_t color[3];
+	int32_t center[3];
+	float circ, score;
+} VphMatch;
+
+/* The tunables of Resources.cpp:189-209 that this stage reads, plus the GCSocket heights (udpsocket.h:122-128). */
+typedef struct VphConfig {
+	int32_t cam_id;
+	double min_tracking_radius, max_bot_acceleration /* mm/s^2 */, min_score, min_cam_edge_distance;
+	float min_confidence, clipping_tolerance, geometry_tolerance, reference_force, history_force;
+	int32_t reference_colors[6][3]; /* orange, field, yellow, blue, green, pink */
+	double max_bot_height, default_bot_height, yellow_bot_height, blue_bot_height;
+} VphConfig;
+
+typedef struct VphTracked { /* udpsocket.h:57-64 */
+	int32_t id;
+	double timestamp;
+	float x, y, z, w, vx, vy, vz, vw, confidence;
+	int32_t age;
+} VphTracked;
+
+typedef struct VphBall { /* SSL_DetectionBall, the fields hypothesis.cpp:69-80 sets */
+	float confidence, x, y, pixel_x, pixel_y;
+} VphBall;
+
+typedef struct VphRobot { /* SSL_DetectionRobot, hypothesis.cpp:140-153 */
+	float confidence;
+	uint32_t robot_id;
+	float x, y, orientation, pixel_x, pixel_y, height;
+} VphRobot;
+
+typedef struct VphFrameHeader { /* SSL_DetectionFrame scalars, main.cpp:345-351,364-368 */
+	uint32_t frame_number, camera_id;
+	double t_capture, t_sent, t_capture_camera;
+	int32_t has_t_capture_camera;
+	int32_t n_balls, n_robots_yellow, n_robots_blue, n_offsets;
+} VphFrameHeader;
+
+void vph_config_defaults(VphConfig* cfg); /* Resources.cpp:84-85,189-209 defaults, shipped robot-heights.yml */
+VphDetector* vph_detector_create(const VphConfig* cfg);
+void vph_detector_destroy(VphDetector* d);
+
+/* Perspective::geometryCheck (Perspective.cpp:35-125) for one camera calibration + the field description.
+ * calib = {focal, ppx, ppy, distortion, q0, q1, q2, q3, tx, ty, tz}; field = {length, width, boundary, boundary_goal_line or -1,
+ * line_thickness}; lines = n_lines x {p1x, p1y, p2x, p2y}; arcs = n_arcs x {cx, cy, radius, a1, a2}. */
+int vph_detector_set_geometry(VphDetector* d, const float calib[11], int calib_w, int calib_h, int img_w, int img_h, float resampling_factor, const int32_t field[5],
+		float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs);
+
+/* main.cpp:303-311: CLMatch (22 bytes packed) -> Match with Perspective::flat2field applied */
+int vph_matches_from_cl(const VphDetector* d, const VpMatch* in, int n, VphMatch* out);
+
+/* VisionSocket::getTrackedObjects / getReceivedOffsets (udpsocket.h:77,81) as settable state */
+int vph_detector_set_tracked(VphDetector* d, uint32_t cam, const VphTracked* objs, int n);
+int vph_detector_get_tracked(const VphDetector* d, uint32_t cam, VphTracked* out, int cap); /* returns the count */
+int vph_detector_set_offsets(VphDetector* d, const float* offsets, int n);
+/* the adaptive colours r.orange, field, yellow, blue, green, pink, fieldLineColor (Resources.h:59-65): set != 0 writes them */
+int vph_detector_colors(VphDetector* d, int32_t colors[7][3], int set);
+
+/* main.cpp:319-362: hypotheses, filters, colour update, detection frame.  The frame stays in the detector. */
+int vph_detect(VphDetector* d, const VphMatch* matches, int n, uint32_t frame_id, double start_time, double img_timestamp);
+int vph_frame_header(const VphDetector* d, VphFrameHeader* out);
+int vph_frame_set_t_sent(VphDetector* d, double t_sent); /* main.cpp:364-368 */
+int vph_frame_balls(const VphDetector* d, VphBall* out, int cap);
+int vph_frame_robots(const VphDetector* d, int blue, VphRobot* out, int cap);
+int vph_frame_offsets(const VphDetector* d, float* out, int cap);
+
+/* VisionSocket::detectionTracking (udpsocket.cpp:204-256) applied to the detector's current frame */
+int vph_track(VphDetector* d);
+
+/* SSL_WrapperPacket{detection, source = SSL_SOURCE_VISION_PROCESSOR} (socket->send(wrapper), main.cpp:370): returns the length,
+ * or -needed when cap is too small. */
+int vph_encode(const VphDetector* d, uint8_t* buf, int cap);
+/* VisionSocket::parse (udpsocket.cpp:146-154): 1 = packet carried a detection (now the current frame), 0 = none, <0 malformed */
+int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source);
+
+/* building blocks, exported for the unit tests */
+float vph_atan2_fast(float y, float x);                                                              /* hypothesis.cpp:35-58 */
+int vph_kmeans(const int32_t contrast[3], const int32_t* values, int n, int32_t c1[3], int32_t c2[3]); /* kmeans.cpp:19-90 */
+int vph_kdtree_range(const float* points_xy, int n, float px, float py, float radius, int32_t* out_idx, int cap); /* kdtree.cpp */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_HOST_H */

@@ -13,10 +13,10 @@ ROOT = cases.ROOT
 PKG = os.path.join(ROOT, "vision-processor_amd")
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "vp_hip.h")).read()
+def declared_functions(header="vp_hip.h", prefix="vp_"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(vp_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", src)))
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +42,17 @@ def test_libraries_export_every_declared_symbol(built):
             assert hasattr(hip, f), f
 
 
+def test_host_library_exports_the_detection_stage(built):
+    """include/vp_host.h (blob list -> SSL_DetectionFrame -> wire bytes) lives in libvp_host.so, which needs no GPU."""
+    host = C.CDLL(os.path.join(PKG, "libvp_host.so"))
+    fns = declared_functions("vp_host.h", "vph_")
+    assert len(fns) >= 20 and "vph_detect" in fns and "vph_encode" in fns
+    missing = [f for f in fns if not hasattr(host, f)]
+    assert not missing, missing
+    out = subprocess.run(["ldd", os.path.join(PKG, "libvp_host.so")], capture_output=True, text=True).stdout
+    assert "amdhip" not in out and "vp_hip" not in out
+
+
 def test_product_does_not_link_the_oracle(built):
     for so in ("libvp_hip.so", "libvp_host.so"):
         out = subprocess.run(["ldd", os.path.join(PKG, so)], capture_output=True, text=True).stdout
@@ -50,7 +61,7 @@ def test_product_does_not_link_the_oracle(built):
         for fn in files:
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
-                assert "import oracle" not in text and "vp_oracle.h" not in text and "libvporacle" not in text, fn
+                assert "import oracle" not in text and "vp_oracle.h" not in text and "libvporacle" not in text and "import detect_oracle" not in text, fn
 
 
 def test_no_gpu_means_loud_failure(built):

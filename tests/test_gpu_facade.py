@@ -34,11 +34,12 @@ def run_loop(cfg, frames, seed, mode, tmp_path, debug_dump=None):
             hdr = f.read(32)
             if len(hdr) < 32:
                 break
-            frame_id, n, c0, c1, c2, fw, fh, _ = struct.unpack("8i", hdr)
+            frame_id, n, c0, c1, c2, fw, fh, wire_len = struct.unpack("8i", hdr)
             fs, ox, oy, _ = struct.unpack("4f", f.read(16))
             m = np.frombuffer(f.read(22 * n), O.MATCH_DTYPE)
             pos = np.frombuffer(f.read(8 * n), np.float32).reshape(n, 2)
-            recs.append(dict(frame=frame_id, counter=np.array([c0, c1, c2], np.int32), fw=fw, fh=fh, fs=fs, ox=ox, oy=oy, matches=m, pos=pos))
+            packet = f.read(wire_len)  # the SSL_WrapperPacket the reference would hand to socket->send (main.cpp:370)
+            recs.append(dict(frame=frame_id, counter=np.array([c0, c1, c2], np.int32), fw=fw, fh=fh, fs=fs, ox=ox, oy=oy, matches=m, pos=pos, packet=packet))
     return recs, out.stdout
 
 
@@ -99,3 +100,47 @@ def test_debug_and_stream_views(port, cfg, tmp_path):
     assert np.array_equal(bufs[1], port.quad2nv12(planes, cfg.layout, 1))
     assert np.array_equal(bufs[2], port.rgba2nv12(flat))
     assert np.array_equal(bufs[3], port.f2nv12(bc))
+
+
+@pytest.mark.parametrize("mode", ["direct", "calib"])
+def test_frame_loop_emits_the_oracles_detection_packets(mode, tmp_path):
+    """main.cpp:319-370 behind the facade: every frame's SSL_WrapperPacket, parsed by google.protobuf, equals what the CPU
+    checker (oracle/detect_oracle.py: hypotheses, colour model and tracker carried from frame to frame) derives from the same
+    blob list -- binary32 fields bit for bit.  (Parity of this CPU stage against the reference itself is unpinned.)"""
+    import detect_oracle as D
+    import test_detection_stage as S
+    import test_wire_format as W
+    cfg = cfgs.T_MID
+    frames = 4
+    recs, stdout = run_loop(cfg, frames, 80, mode, tmp_path)
+    assert len(recs) == frames
+    model = cfg.model()
+    calib = (model.f, model.p[0], model.p[1], model.d, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, model.c[2])  # nadir: q = (x -1, y 0, z 0, w 0), t = R (-pos)
+    cam = D.Camera(calib, (cfg.qw, cfg.qh), (cfg.qw, cfg.qh))
+    field = dict(field_length=int(cfg.field_len), field_width=int(cfg.field_wid), boundary_width=300) if mode == "calib" else {}
+    r = D.Res(cam, **field)
+    total_bots = 0
+    for k, rec in enumerate(recs):
+        m = rec["matches"]
+        matches = [dict(pos=(np.float32(px), np.float32(py)), color=tuple(int(v) for v in mm["color"]), center=tuple(int(v) for v in mm["center"]), circ=np.float32(mm["circ"]),
+                        score=np.float32(mm["score"])) for mm, (px, py) in zip(m, rec["pos"])]
+        t = (k + 1) / 30.0  # SyntheticCamera::getTime after readImage
+        want = D.detect_frame(r, matches, k + 1, t, t)
+        want["t_sent"] = t
+        pkt = W.Wrapper()
+        pkt.ParseFromString(rec["packet"])
+        assert pkt.IsInitialized() and pkt.source == 3
+        d = pkt.detection
+        got = dict(frame_number=d.frame_number, camera_id=d.camera_id, t_capture=d.t_capture, t_capture_camera=d.t_capture_camera if d.HasField("t_capture_camera") else None,
+                   t_offsets=np.asarray(d.t_offsets, np.float32),
+                   balls=[dict(confidence=b.confidence, x=b.x, y=b.y, pixel_x=b.pixel_x, pixel_y=b.pixel_y) for b in d.balls],
+                   robots_yellow=[dict(confidence=b.confidence, robot_id=b.robot_id, x=b.x, y=b.y, orientation=b.orientation, pixel_x=b.pixel_x, pixel_y=b.pixel_y, height=b.height)
+                                  for b in d.robots_yellow],
+                   robots_blue=[dict(confidence=b.confidence, robot_id=b.robot_id, x=b.x, y=b.y, orientation=b.orientation, pixel_x=b.pixel_x, pixel_y=b.pixel_y, height=b.height)
+                                for b in d.robots_blue])
+        S.assert_frames_equal(got, want)
+        assert d.t_sent == t
+        D.detection_tracking(r, want)
+        total_bots += len(d.robots_yellow) + len(d.robots_blue)
+        assert f"frame {k + 1}: {len(m)} blobs {len(d.balls)} balls {len(d.robots_yellow) + len(d.robots_blue)} bots" in stdout
+    assert total_bots >= frames  # the rendered robots are found in every frame

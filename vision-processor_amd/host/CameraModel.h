@@ -10,6 +10,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 #include "vp_hip.h"
 
@@ -33,12 +34,19 @@ struct CameraCalibration {
 	uint32_t pixel_image_width = 0, pixel_image_height = 0;
 };
 
-// SSL_GeometryFieldSize -- the fields Perspective/CameraModel read
+// SSL_FieldLineSegment / SSL_FieldCircularArc (proto/ssl_vision_geometry.proto:14-41) -- the fields colorupdate.cpp:21-55 reads
+struct FieldLine { Vec2f p1, p2; };
+struct FieldArc { Vec2f center; float radius = 0.f, a1 = 0.f, a2 = 0.f; };
+
+// SSL_GeometryFieldSize -- the fields Perspective/CameraModel and the hypothesis stage read
 struct FieldSize {
 	int field_length = 9000, field_width = 6000, boundary_width = 300;
 	bool has_boundary_width_goal_line = false;
 	int boundary_width_goal_line = 0;
 	float ball_radius = 21.5f, max_robot_radius = 90.f;
+	int line_thickness = 0; // optional int32 without a default (:69-70)
+	std::vector<FieldLine> field_lines;
+	std::vector<FieldArc> field_arcs;
 };
 
 const float CENTER_BLOB_RADIUS = 25.0f; // pattern.h:55

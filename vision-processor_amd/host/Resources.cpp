@@ -12,7 +12,9 @@ std::shared_ptr<RawImage> SyntheticCamera::readImage() {
 	return std::make_shared<RawImage>(fmt, qw, qh, getTime(), raw.data());
 }
 
-Resources::Resources(std::unique_ptr<SyntheticCamera> cam, int camId, float geometryTolerance): camera(std::move(cam)), camId(camId) {
+Resources::Resources(std::unique_ptr<SyntheticCamera> cam, int camId_, float geometryTolerance_): camera(std::move(cam)) {
+	camId = camId_;
+	geometryTolerance = geometryTolerance_;
 	openCl = std::make_shared<OpenCL>();
 	perspective = std::make_shared<vp::Perspective>(camId, geometryTolerance);
 	const char* layout = camera->format().kernelOptions; // Resources.cpp:121-126: the format-dependent kernels get -DRGGB/-DGRBG/-DBGR

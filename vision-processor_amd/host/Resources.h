@@ -7,6 +7,7 @@
 #include <string>
 
 #include "CameraModel.h"
+#include "blobs/detection.h"
 #include "cl_kernels.h"
 #include "opencl.h"
 
@@ -46,20 +47,19 @@ private:
 	int frame = 0;
 };
 
-class Resources {
+// vp::BlobResources carries the members the CPU hypothesis stage reads (camId, minScore, minConfidence, the colour model,
+// maxBotHeight, perspective, tracked objects ...: blobs/detection.h); the launch half adds the rest.
+class Resources: public vp::BlobResources {
 public:
 	Resources(std::unique_ptr<SyntheticCamera> camera, int camId, float geometryTolerance);
 
 	std::unique_ptr<SyntheticCamera> camera;
-	int camId;
 	double minCircularity = 15.0; // thresholds.circularity (Resources.cpp:190)
-	double minScore = 5.0;        // applied on the CPU after the list stage (main.cpp:342); the kernel always gets 0.0f
+	// minScore (BlobResources) is applied on the CPU after the list stage (main.cpp:342); the kernel always gets 0.0f
 	int maxBlobs = 2000;          // thresholds.blobs (Resources.cpp:84)
 	float resamplingFactor = 1.0f;
-	double maxBotHeight = 180.0;  // gcSocket->maxBotHeight with the shipped robot-heights.yml
 	bool debugImages = false;
 
-	std::shared_ptr<vp::Perspective> perspective;
 	std::shared_ptr<OpenCL> openCl;
 
 	cl::Kernel raw2quadKernel, resampling, gradientDot, satHorizontal, satVertical, satBlobCenter;

@@ -1,0 +1,262 @@
+// Flat C binding of the blob -> detection stage (include/vp_host.h).
+#include <algorithm>
+#include <cstring>
+
+#include "detection.h"
+#include "vp_host.h"
+
+struct VphDetector {
+	vp::BlobResources r;
+	vp::DetectionFrame frame;
+};
+
+namespace {
+
+vp::Vec3i v3(const int32_t* c) { return {c[0], c[1], c[2]}; }
+void put3(int32_t* o, const vp::Vec3i& c) {
+	o[0] = c.x;
+	o[1] = c.y;
+	o[2] = c.z;
+}
+
+} // namespace
+
+extern "C" {
+
+void vph_config_defaults(VphConfig* cfg) {
+	const vp::BlobResources d;
+	cfg->cam_id = d.camId;
+	cfg->min_tracking_radius = d.minTrackingRadius;
+	cfg->max_bot_acceleration = d.maxBotAcceleration;
+	cfg->min_score = d.minScore;
+	cfg->min_cam_edge_distance = d.minCamEdgeDistance;
+	cfg->min_confidence = d.minConfidence;
+	cfg->clipping_tolerance = d.clippingTolerance;
+	cfg->geometry_tolerance = d.geometryTolerance;
+	cfg->reference_force = d.referenceForce;
+	cfg->history_force = d.historyForce;
+	const vp::Vec3i refs[6] = {d.orangeReference, d.fieldReference, d.yellowReference, d.blueReference, d.greenReference, d.pinkReference};
+	for(int i = 0; i < 6; i++) put3(cfg->reference_colors[i], refs[i]);
+	cfg->max_bot_height = d.maxBotHeight;
+	cfg->default_bot_height = d.defaultBotHeight;
+	cfg->yellow_bot_height = d.yellowBotHeight;
+	cfg->blue_bot_height = d.blueBotHeight;
+}
+
+VphDetector* vph_detector_create(const VphConfig* cfg) {
+	if(!cfg) return nullptr;
+	VphDetector* d = new VphDetector();
+	vp::BlobResources& r = d->r;
+	r.camId = cfg->cam_id;
+	r.minTrackingRadius = cfg->min_tracking_radius;
+	r.maxBotAcceleration = cfg->max_bot_acceleration;
+	r.minScore = cfg->min_score;
+	r.minCamEdgeDistance = cfg->min_cam_edge_distance;
+	r.minConfidence = cfg->min_confidence;
+	r.clippingTolerance = cfg->clipping_tolerance;
+	r.geometryTolerance = cfg->geometry_tolerance;
+	r.referenceForce = cfg->reference_force;
+	r.historyForce = cfg->history_force;
+	r.orange = r.orangeReference = v3(cfg->reference_colors[0]); // Resources.cpp:89-95
+	r.field = r.fieldReference = v3(cfg->reference_colors[1]);
+	r.yellow = r.yellowReference = v3(cfg->reference_colors[2]);
+	r.blue = r.blueReference = v3(cfg->reference_colors[3]);
+	r.green = r.greenReference = v3(cfg->reference_colors[4]);
+	r.pink = r.pinkReference = v3(cfg->reference_colors[5]);
+	r.fieldLineColor = r.fieldReference;
+	r.maxBotHeight = cfg->max_bot_height;
+	r.defaultBotHeight = cfg->default_bot_height;
+	r.yellowBotHeight = cfg->yellow_bot_height;
+	r.blueBotHeight = cfg->blue_bot_height;
+	r.perspective = std::make_shared<vp::Perspective>(r.camId, r.geometryTolerance);
+	return d;
+}
+
+void vph_detector_destroy(VphDetector* d) { delete d; }
+
+int vph_detector_set_geometry(VphDetector* d, const float calib[11], int calib_w, int calib_h, int img_w, int img_h, float resampling_factor, const int32_t field[5],
+		float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs) {
+	if(!d || !calib || !field || img_w <= 1 || img_h <= 1 || calib_w <= 0 || calib_h <= 0 || n_lines < 0 || n_arcs < 0 || (n_lines && !lines) || (n_arcs && !arcs)) return VP_ERR_INVALID;
+	vp::FieldSize f;
+	f.field_length = field[0];
+	f.field_width = field[1];
+	f.boundary_width = field[2];
+	f.has_boundary_width_goal_line = field[3] >= 0;
+	f.boundary_width_goal_line = field[3] >= 0 ? field[3] : 0;
+	f.line_thickness = field[4];
+	f.ball_radius = ball_radius;
+	f.max_robot_radius = max_robot_radius;
+	for(int i = 0; i < n_lines; i++) f.field_lines.push_back({{lines[4 * i], lines[4 * i + 1]}, {lines[4 * i + 2], lines[4 * i + 3]}});
+	for(int i = 0; i < n_arcs; i++) f.field_arcs.push_back({{arcs[5 * i], arcs[5 * i + 1]}, arcs[5 * i + 2], arcs[5 * i + 3], arcs[5 * i + 4]});
+	vp::CameraCalibration c;
+	c.camera_id = (uint32_t)d->r.camId;
+	c.focal_length = calib[0];
+	c.principal_point_x = calib[1];
+	c.principal_point_y = calib[2];
+	c.distortion = calib[3];
+	c.q0 = calib[4];
+	c.q1 = calib[5];
+	c.q2 = calib[6];
+	c.q3 = calib[7];
+	c.tx = calib[8];
+	c.ty = calib[9];
+	c.tz = calib[10];
+	c.pixel_image_width = (uint32_t)calib_w;
+	c.pixel_image_height = (uint32_t)calib_h;
+	d->r.perspective->setGeometry(f, &c, 1);
+	d->r.perspective->geometryCheck(img_w, img_h, d->r.maxBotHeight, resampling_factor);
+	d->r.ballRadius = ball_radius; // udpsocket.cpp:123-124
+	return d->r.perspective->geometryVersion ? VP_OK : VP_ERR_INVALID;
+}
+
+int vph_matches_from_cl(const VphDetector* d, const VpMatch* in, int n, VphMatch* out) {
+	if(!d || n < 0 || (n && (!in || !out))) return VP_ERR_INVALID;
+	for(int i = 0; i < n; i++) {
+		const VpMatch& m = in[i];
+		const vp::Vec2f pos = d->r.perspective->flat2field({m.x, m.y});
+		out[i] = {pos.x, pos.y, {m.color[0], m.color[1], m.color[2]}, {m.center[0], m.center[1], m.center[2]}, m.circ, m.score};
+	}
+	return VP_OK;
+}
+
+int vph_detector_set_tracked(VphDetector* d, uint32_t cam, const VphTracked* objs, int n) {
+	if(!d || n < 0 || (n && !objs)) return VP_ERR_INVALID;
+	std::vector<vp::TrackingState>& v = d->r.trackedObjects[cam];
+	v.clear();
+	for(int i = 0; i < n; i++) {
+		const VphTracked& t = objs[i];
+		v.push_back({t.id, t.timestamp, t.x, t.y, t.z, t.w, t.vx, t.vy, t.vz, t.vw, t.confidence, t.age});
+	}
+	return VP_OK;
+}
+
+int vph_detector_get_tracked(const VphDetector* d, uint32_t cam, VphTracked* out, int cap) {
+	if(!d) return VP_ERR_INVALID;
+	const auto it = d->r.trackedObjects.find(cam);
+	if(it == d->r.trackedObjects.end()) return 0;
+	const int n = (int)it->second.size();
+	for(int i = 0; i < std::min(n, cap); i++) {
+		const vp::TrackingState& t = it->second[i];
+		out[i] = {t.id, t.timestamp, t.x, t.y, t.z, t.w, t.vx, t.vy, t.vz, t.vw, t.confidence, t.age};
+	}
+	return n;
+}
+
+int vph_detector_set_offsets(VphDetector* d, const float* offsets, int n) {
+	if(!d || n < 0 || (n && !offsets)) return VP_ERR_INVALID;
+	d->r.receivedOffsets.assign(offsets, offsets + n);
+	return VP_OK;
+}
+
+int vph_detector_colors(VphDetector* d, int32_t colors[7][3], int set) {
+	if(!d || !colors) return VP_ERR_INVALID;
+	vp::Vec3i* slots[7] = {&d->r.orange, &d->r.field, &d->r.yellow, &d->r.blue, &d->r.green, &d->r.pink, &d->r.fieldLineColor};
+	for(int i = 0; i < 7; i++) {
+		if(set) *slots[i] = v3(colors[i]);
+		else put3(colors[i], *slots[i]);
+	}
+	return VP_OK;
+}
+
+int vph_detect(VphDetector* d, const VphMatch* matches, int n, uint32_t frame_id, double start_time, double img_timestamp) {
+	if(!d || n < 0 || (n && !matches)) return VP_ERR_INVALID;
+	if(!d->r.perspective->geometryVersion) return VP_ERR_INVALID; // main.cpp:277: no geometry, no detection
+	std::vector<vp::Match> ms;
+	ms.reserve((size_t)n);
+	for(int i = 0; i < n; i++) {
+		const VphMatch& m = matches[i];
+		ms.push_back({{m.x, m.y}, v3(m.color), v3(m.center), m.circ, m.score});
+	}
+	d->frame = vp::detectFrame(d->r, ms, frame_id, start_time, img_timestamp);
+	return VP_OK;
+}
+
+int vph_frame_header(const VphDetector* d, VphFrameHeader* out) {
+	if(!d || !out) return VP_ERR_INVALID;
+	const vp::DetectionFrame& f = d->frame;
+	*out = {f.frame_number, f.camera_id, f.t_capture, f.t_sent, f.t_capture_camera, f.has_t_capture_camera ? 1 : 0, (int32_t)f.balls.size(), (int32_t)f.robots_yellow.size(),
+			(int32_t)f.robots_blue.size(), (int32_t)f.t_offsets.size()};
+	return VP_OK;
+}
+
+int vph_frame_set_t_sent(VphDetector* d, double t_sent) {
+	if(!d) return VP_ERR_INVALID;
+	d->frame.t_sent = t_sent;
+	return VP_OK;
+}
+
+int vph_frame_balls(const VphDetector* d, VphBall* out, int cap) {
+	if(!d) return VP_ERR_INVALID;
+	const int n = (int)d->frame.balls.size();
+	for(int i = 0; i < std::min(n, cap); i++) {
+		const vp::DetectionBall& b = d->frame.balls[i];
+		out[i] = {b.confidence, b.x, b.y, b.pixel_x, b.pixel_y};
+	}
+	return n;
+}
+
+int vph_frame_robots(const VphDetector* d, int blue, VphRobot* out, int cap) {
+	if(!d) return VP_ERR_INVALID;
+	const std::vector<vp::DetectionRobot>& v = blue ? d->frame.robots_blue : d->frame.robots_yellow;
+	const int n = (int)v.size();
+	for(int i = 0; i < std::min(n, cap); i++) out[i] = {v[i].confidence, v[i].robot_id, v[i].x, v[i].y, v[i].orientation, v[i].pixel_x, v[i].pixel_y, v[i].height};
+	return n;
+}
+
+int vph_frame_offsets(const VphDetector* d, float* out, int cap) {
+	if(!d) return VP_ERR_INVALID;
+	const int n = (int)d->frame.t_offsets.size();
+	for(int i = 0; i < std::min(n, cap); i++) out[i] = d->frame.t_offsets[i];
+	return n;
+}
+
+int vph_track(VphDetector* d) {
+	if(!d) return VP_ERR_INVALID;
+	vp::detectionTracking(d->r, d->frame);
+	return VP_OK;
+}
+
+int vph_encode(const VphDetector* d, uint8_t* buf, int cap) {
+	if(!d) return VP_ERR_INVALID;
+	const std::vector<uint8_t> bytes = vp::encodeWrapperPacket(d->frame);
+	if((int)bytes.size() > cap || !buf) return -(int)bytes.size();
+	std::memcpy(buf, bytes.data(), bytes.size());
+	return (int)bytes.size();
+}
+
+int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source) {
+	if(!d || len < 0 || (len && !buf)) return VP_ERR_INVALID;
+	vp::DetectionFrame f;
+	bool has = false;
+	int src = 0;
+	if(!vp::decodeWrapperPacket(buf, (size_t)len, f, has, src)) return VP_ERR_INVALID;
+	if(source) *source = src;
+	if(has) d->frame = f;
+	return has ? 1 : 0;
+}
+
+float vph_atan2_fast(float y, float x) { return vp::atan2_fast(y, x); }
+
+int vph_kmeans(const int32_t contrast[3], const int32_t* values, int n, int32_t c1[3], int32_t c2[3]) {
+	std::vector<vp::Vec3i> vs;
+	for(int i = 0; i < n; i++) vs.push_back(v3(values + 3 * i));
+	vp::Vec3i a = v3(c1), b = v3(c2);
+	const bool ok = vp::kMeans(v3(contrast), vs, a, b);
+	put3(c1, a);
+	put3(c2, b);
+	return ok ? 1 : 0;
+}
+
+int vph_kdtree_range(const float* pts, int n, float px, float py, float radius, int32_t* out_idx, int cap) {
+	if(n <= 0) return 0;
+	std::vector<vp::Match> ms((size_t)n);
+	for(int i = 0; i < n; i++) ms[i].pos = {pts[2 * i], pts[2 * i + 1]};
+	vp::KDTree tree(&ms[0]);
+	for(int i = 1; i < n; i++) tree.insert(&ms[i]);
+	std::vector<vp::Match*> found;
+	tree.rangeSearch(found, {px, py}, radius);
+	for(int i = 0; i < std::min((int)found.size(), cap); i++) out_idx[i] = (int32_t)(found[i] - &ms[0]);
+	return (int)found.size();
+}
+
+} // extern "C"

@@ -1,0 +1,193 @@
+// Blob list -> SSL_DetectionFrame: the CPU stage that follows the GPU hot path in the reference.
+//
+// Restates src/blobs/{match.h,kdtree.*,kmeans.*,hypothesis.*,colorupdate.*}, the hypothesis generators and filters of
+// src/main.cpp:43-241, the per-frame sequence main.cpp:319-359, and the detection tracker of src/udpsocket.cpp:165-256,
+// Eigen-free and protobuf-free: Eigen vectors are the PODs of ../CameraModel.h, the protobuf messages are plain structs,
+// the polymorphic unique_ptr lists are value vectors (same element order, same erase semantics).
+//
+// PARITY UNPINNED: the reference host code cannot be built in this image (Eigen, protobuf, yaml-cpp absent) and ships no
+// test or fixture for this stage; the reference is also compiled with -ffast-math -march=native (CMakeLists.txt:28), so its
+// own float results are compiler-dependent.  This restatement is strict binary32, one rounding per source operation
+// (-ffp-contract=off), evaluation order as written in the cited lines.  tests/ hold it to an independent numpy/libm
+// restatement (oracle/detect_oracle.py), which pins the two against each other and nothing more.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "../CameraModel.h"
+
+namespace vp {
+
+struct Vec3i {
+	int x = 0, y = 0, z = 0;
+	bool operator==(const Vec3i& o) const { return x == o.x && y == o.y && z == o.z; }
+	bool operator!=(const Vec3i& o) const { return !(*this == o); }
+};
+inline int sqDiff(const Vec3i& a, const Vec3i& b) { // (a - b).squaredNorm()
+	const int dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+	return dx * dx + dy * dy + dz * dz;
+}
+
+struct Match { // blobs/match.h:22-30 -- pos already in field coordinates (Perspective::flat2field, main.cpp:306)
+	Vec2f pos;
+	Vec3i color;
+	Vec3i center;
+	float circ = 0.f;
+	float score = 0.f;
+};
+
+// blobs/kdtree.{h,cpp}: unbalanced 2-d tree in insertion order, split axis alternating per level.  Stored as an index
+// arena instead of linked unique_ptr nodes; insert() and rangeSearch() visit nodes in the reference's order (node, left
+// subtree, right subtree), which fixes the order of the result vector.
+class KDTree {
+public:
+	KDTree() = default;
+	explicit KDTree(Match* root) { nodes.push_back({root, -1, -1, 0}); }
+	void insert(Match* m);
+	void rangeSearch(std::vector<Match*>& values, const Vec2f& point, float radius) const;
+	int getSize() const { return (int)nodes.size(); }
+
+private:
+	struct Node {
+		Match* data;
+		int left, right, dim;
+	};
+	std::vector<Node> nodes;
+	void search(int n, std::vector<Match*>& values, const Vec2f& point, float radius) const;
+};
+
+bool kMeans(const Vec3i& contrast, const std::vector<Vec3i>& values, Vec3i& c1, Vec3i& c2); // blobs/kmeans.cpp:19-90
+float atan2_fast(float y, float x);                                                            // blobs/hypothesis.cpp:21-58
+
+// pattern.h:18-61
+extern const int patterns[16];
+extern const int patternLUT[16];
+extern const float patternAnglesb2b[25];
+extern const Vec2f patternPos[5];
+const float MIN_ROBOT_RADIUS = 85.0f;
+const float MIN_ROBOT_FRONT_DISTANCE = 55.0f;
+const float MIN_ROBOT_OPENING_ANGLE = 0.86708f;
+
+struct TrackingState { // udpsocket.h:57-64
+	int id = 0; // -1: ball, 0-15: yellow bot, 16-31: blue bot
+	double timestamp = 0.0;
+	float x = 0, y = 0, z = 0, w = 0;
+	float vx = 0, vy = 0, vz = 0, vw = 0;
+	float confidence = 0;
+	int age = 0;
+};
+
+// proto/ssl_vision_detection.proto as plain structs (only the fields the reference sets: main.cpp:345-362, hypothesis.cpp:69-80,140-153)
+struct DetectionBall {
+	float confidence, x, y, pixel_x, pixel_y;
+};
+struct DetectionRobot {
+	float confidence;
+	uint32_t robot_id;
+	float x, y, orientation, pixel_x, pixel_y, height;
+};
+struct DetectionFrame {
+	uint32_t frame_number = 0;
+	double t_capture = 0.0, t_sent = 0.0;
+	bool has_t_capture_camera = false;
+	double t_capture_camera = 0.0;
+	std::vector<float> t_offsets;
+	uint32_t camera_id = 0;
+	std::vector<DetectionBall> balls;
+	std::vector<DetectionRobot> robots_yellow, robots_blue;
+};
+
+// The members of the reference's Resources / GCSocket / VisionSocket that this stage reads and writes (Resources.h:43-73,
+// udpsocket.h:106,122-128), defaults as in Resources.cpp:84-85,189-209 and the shipped robot-heights.yml.
+struct BlobResources {
+	int camId = 0;
+	double minTrackingRadius = 20.0;
+	double maxBotAcceleration = 6500.0; // mm/s^2 (1000 * tracking.max_bot_acceleration)
+	double minScore = 5.0;
+	double minCamEdgeDistance = 170.0;
+	float minConfidence = 0.2f;
+	float clippingTolerance = 10.0f;
+	float geometryTolerance = 10.0f;
+	float referenceForce = 0.1f;
+	float historyForce = 0.7f;
+	Vec3i orangeReference{192, 128, 64}, fieldReference{128, 128, 128}, yellowReference{255, 128, 0}, blueReference{0, 128, 255}, greenReference{0, 255, 128},
+			pinkReference{255, 0, 128};
+	Vec3i orange = orangeReference, field = fieldReference, yellow = yellowReference, blue = blueReference, green = greenReference, pink = pinkReference;
+	Vec3i fieldLineColor = fieldReference;
+
+	// gcSocket
+	double maxBotHeight = 180.0;
+	double defaultBotHeight = 143.0;
+	double yellowBotHeight = 143.0;
+	double blueBotHeight = 143.0;
+
+	// socket: what VisionSocket::getTrackedObjects / getReceivedOffsets hand out
+	std::map<unsigned int, std::vector<TrackingState>> trackedObjects;
+	std::vector<float> receivedOffsets;
+	float ballRadius = 21.5f; // udpsocket.h:98
+
+	std::shared_ptr<Perspective> perspective;
+};
+
+struct BallHypothesis { // blobs/hypothesis.h:26-41
+	const Match* blob = nullptr;
+	Vec2f pos;
+	float score = 1.0f;
+};
+
+struct BotHypothesis { // blobs/hypothesis.h:44-91: base + Detection / Tracked variants, flattened
+	const Match* blobs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	Vec2f pos;
+	float orientation = 0;
+	float score = 1.0f;
+	float offsetScore = 1.0f;
+	int botId = -1;
+	int blobAmount = 0;
+	bool tracked = false;
+	float trackedScore = 0.f;
+	Vec3f trackedPosition;
+};
+
+// hypothesis.cpp
+BallHypothesis makeBallHypothesis(const BlobResources& r, const Match* blob);                                                   // :61-63
+void recalcPostColorCalib(const BlobResources& r, BallHypothesis& ball);                                                       // :65-68
+void recalcPostColorCalib(const BlobResources& r, BotHypothesis& bot);                                                         // :212-214, :252-255
+BotHypothesis makeDetectionBotHypothesis(const BlobResources& r, const Match* a, const Match* b, const Match* c, const Match* d, const Match* e); // :208-210
+BotHypothesis makeTrackedBotHypothesis(const BlobResources& r, const TrackingState& tracked, const Vec3f& trackedPosition, const Match* a, const Match* b, const Match* c,
+		const Match* d, const Match* e);                                                                                      // :241-250
+bool isClipping(const BlobResources& r, const BotHypothesis& self, const BotHypothesis& other);                                // :108-122
+bool isClipping(const BlobResources& r, const BotHypothesis& self, const BallHypothesis& ball);                                // :124-139
+void addToDetectionFrame(const BlobResources& r, const BallHypothesis& ball, DetectionFrame& detection);                       // :69-80
+void addToDetectionFrame(const BlobResources& r, const BotHypothesis& bot, DetectionFrame& detection);                         // :140-153
+
+// colorupdate.cpp:81-141
+void updateColors(BlobResources& r, const std::vector<BotHypothesis>& bestBotModels, const std::vector<BallHypothesis>& ballCandidates);
+
+// main.cpp:43-241
+void generateAngleSortedBotHypotheses(const BlobResources& r, std::vector<BotHypothesis>& bots, std::vector<Match>& matches, KDTree& blobs);
+void generateRadiusSearchTrackedBotHypotheses(const BlobResources& r, std::vector<BotHypothesis>& bots, std::vector<Match>& matches, KDTree& blobs, double currentTimestamp);
+void filterHypothesesScore(std::vector<BotHypothesis>& bots, float threshold);
+void filterHypothesesScore(std::vector<BallHypothesis>& balls, float threshold);
+void filterStddevScore(std::vector<BallHypothesis>& balls, float threshold);
+void filterBallsAtCamEdge(const BlobResources& r, std::vector<BallHypothesis>& balls);
+void filterClippingBotBotHypotheses(const BlobResources& r, std::vector<BotHypothesis>& bots);
+void generateNonclippingBallHypotheses(const BlobResources& r, const std::vector<BotHypothesis>& bots, std::vector<Match>& matches, std::vector<BallHypothesis>& balls);
+
+// main.cpp:319-362: everything between the read-back of the blob list and socket->send(); t_sent is left for the caller
+// (it is a clock reading).  `matches` must outlive the call only.
+DetectionFrame detectFrame(BlobResources& r, std::vector<Match>& matches, uint32_t frameId, double startTime, double imgTimestamp);
+
+// udpsocket.cpp:165-256 (VisionSocket::detectionTracking): updates r.trackedObjects[detection.camera_id]
+void detectionTracking(BlobResources& r, const DetectionFrame& detection);
+
+// proto2 wire encoding of SSL_WrapperPacket{detection, source = SSL_SOURCE_VISION_PROCESSOR} (proto/ssl_vision_wrapper.proto,
+// ssl_vision_detection.proto), byte-identical to what protobuf's serializer emits for the fields main.cpp:345-362 sets
+// (fields in field-number order, required/optional scalars always written once set, t_offsets unpacked).
+std::vector<uint8_t> encodeWrapperPacket(const DetectionFrame& detection);
+// and back (what VisionSocket::parse needs from a received packet: udpsocket.cpp:146-154); false on malformed input
+bool decodeWrapperPacket(const uint8_t* data, size_t size, DetectionFrame& detection, bool& hasDetection, int& source);
+
+} // namespace vp

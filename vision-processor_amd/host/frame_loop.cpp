@@ -1,6 +1,7 @@
-// The per-frame detection loop of the reference (src/main.cpp:251-317) written against the HIP facade: readImage ->
-// geometryCheck -> raw2quad -> rgba2blobCenter -> zero counters -> blobList -> read back -> flat2field.  Everything after the
-// read-back (hypotheses, sockets, streaming) is CPU post-processing / control plane and out of scope.
+// The per-frame detection loop of the reference (src/main.cpp:251-372) written against the HIP facade: readImage ->
+// geometryCheck -> raw2quad -> rgba2blobCenter -> zero counters -> blobList -> read back -> flat2field -> hypotheses ->
+// SSL_DetectionFrame -> SSL_WrapperPacket bytes -> (own packet looped back into the tracker, as the multicast group does).
+// Sockets and RTP streaming themselves are I/O and out of scope: the packet is written to the dump file instead of sent.
 //
 // usage: vp_frame_loop <layout 0|1|2> <qw> <qh> <camHeight> <visibleLen> <distortion> <fieldLen> <fieldWid> <frames> <seed> <robots> <balls>
 //                      <mode: direct|calib> [direct: fieldScale offX offY fw fh] [dump.bin]
@@ -13,12 +14,7 @@
 
 #include "Resources.h"
 
-struct Match { // src/blobs/match.h: what the CPU stages consume
-	vp::Vec2f pos;
-	int color[3];
-	int center[3];
-	float circ, score;
-};
+using vp::Match; // src/blobs/match.h: what the CPU stages consume
 
 int main(int argc, char* argv[]) {
 	if(argc < 14) {
@@ -80,6 +76,7 @@ int main(int argc, char* argv[]) {
 		frameId++;
 		std::shared_ptr<RawImage> img = r.camera->readImage();
 		if(img == nullptr) break;
+		const double startTime = r.camera->getTime(); // main.cpp:270
 		if(mode != "direct") p.geometryCheck(img->width, img->height, r.maxBotHeight, r.resamplingFactor);
 		std::shared_ptr<CLImage> channels[4];
 		r.raw2quad(*img, channels);
@@ -113,7 +110,9 @@ int main(int argc, char* argv[]) {
 				(float)r.minCircularity, 0.0f, p.listRadius(), r.maxBlobs);
 
 		std::vector<Match> matches; // main.cpp:297-317
+		std::vector<uint8_t> packet;
 		int counts[3];
+		int nBalls = 0, nBots = 0;
 		{
 			CLMap<int> counterMap = counter.read<int>();
 			CLMap<CLMatch> matchMap = matchArray.read<CLMatch>();
@@ -125,17 +124,31 @@ int main(int argc, char* argv[]) {
 			}
 			if(counterMap[0] > r.maxBlobs) WARN("max blob amount reached: " << counterMap[0] << "/" << r.maxBlobs);
 			for(int i = 0; i < 3; i++) counts[i] = counterMap[i];
+			// main.cpp:319-370: hypotheses -> detection frame -> wrapper packet; t_sent is the camera clock (main.cpp:367)
+			vp::DetectionFrame detection = vp::detectFrame(r, matches, frameId, startTime, img->timestamp);
+			detection.t_sent = r.camera->getTime();
+			packet = vp::encodeWrapperPacket(detection); // r.socket->send(wrapper)
+			{ // the multicast group delivers the packet to every camera process including this one: VisionSocket::parse (udpsocket.cpp:146-154)
+				vp::DetectionFrame received;
+				bool hasDetection = false;
+				int source = 0;
+				if(!vp::decodeWrapperPacket(packet.data(), packet.size(), received, hasDetection, source) || !hasDetection) FATAL("own SSL_WrapperPacket does not parse");
+				vp::detectionTracking(r, received);
+			}
+			nBalls = (int)detection.balls.size();
+			nBots = (int)(detection.robots_yellow.size() + detection.robots_blue.size());
 			if(dump) {
-				const int hdr[8] = {(int)frameId, matchAmount, counts[0], counts[1], counts[2], p.reprojectedFieldSize.x, p.reprojectedFieldSize.y, 0};
+				const int hdr[8] = {(int)frameId, matchAmount, counts[0], counts[1], counts[2], p.reprojectedFieldSize.x, p.reprojectedFieldSize.y, (int)packet.size()};
 				fwrite(hdr, sizeof(hdr), 1, dump);
 				const float sc[4] = {p.fieldScale, p.visibleFieldExtent[0], p.visibleFieldExtent[2], 0.f};
 				fwrite(sc, sizeof(sc), 1, dump);
 				fwrite(*matchMap, sizeof(CLMatch), (size_t)matchAmount, dump);
 				for(const Match& m : matches) fwrite(&m.pos, sizeof(float), 2, dump);
+				fwrite(packet.data(), 1, packet.size(), dump);
 			}
 		}
-		printf("frame %u: %zu blobs, counter {%d, %d, %d}, flat %dx%d, fieldScale %.6f\n", frameId, matches.size(), counts[0], counts[1], counts[2], p.reprojectedFieldSize.x,
-				p.reprojectedFieldSize.y, p.fieldScale);
+		printf("frame %u: %zu blobs %d balls %d bots, counter {%d, %d, %d}, flat %dx%d, fieldScale %.6f\n", frameId, matches.size(), nBalls, nBots, counts[0], counts[1], counts[2],
+				p.reprojectedFieldSize.x, p.reprojectedFieldSize.y, p.fieldScale); // main.cpp:365
 		r.openCl->printRuntimes();
 		r.openCl->clearEvents(); // main.cpp:372
 	}

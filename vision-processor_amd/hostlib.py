@@ -65,3 +65,171 @@ def geometry_check(calib, img_w, img_h, calib_w, calib_h, field, ball_radius=21.
         "field_scale": of[0], "extent": [of[1], of[2], of[3], of[4]], "min_blob_radius": of[5], "max_blob_radius": of[6],
         "fw": oi[0], "fh": oi[1], "grad_offset": oi[2], "circle_radius": oi[3], "list_radius": oi[4], "geometry_version": oi[5], "model": m,
     }
+
+
+# ---- blob list -> detection frame (include/vp_host.h) --------------------------------------------
+class VphConfig(C.Structure):
+    _fields_ = [("cam_id", C.c_int32), ("min_tracking_radius", C.c_double), ("max_bot_acceleration", C.c_double), ("min_score", C.c_double),
+                ("min_cam_edge_distance", C.c_double), ("min_confidence", C.c_float), ("clipping_tolerance", C.c_float), ("geometry_tolerance", C.c_float),
+                ("reference_force", C.c_float), ("history_force", C.c_float), ("reference_colors", (C.c_int32 * 3) * 6), ("max_bot_height", C.c_double),
+                ("default_bot_height", C.c_double), ("yellow_bot_height", C.c_double), ("blue_bot_height", C.c_double)]
+
+
+class VphFrameHeader(C.Structure):
+    _fields_ = [("frame_number", C.c_uint32), ("camera_id", C.c_uint32), ("t_capture", C.c_double), ("t_sent", C.c_double), ("t_capture_camera", C.c_double),
+                ("has_t_capture_camera", C.c_int32), ("n_balls", C.c_int32), ("n_robots_yellow", C.c_int32), ("n_robots_blue", C.c_int32), ("n_offsets", C.c_int32)]
+
+
+VPH_MATCH = np.dtype([("x", "<f4"), ("y", "<f4"), ("color", "<i4", 3), ("center", "<i4", 3), ("circ", "<f4"), ("score", "<f4")])
+VPH_TRACKED = np.dtype([("id", "<i4"), ("timestamp", "<f8"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("vx", "<f4"), ("vy", "<f4"), ("vz", "<f4"),
+                        ("vw", "<f4"), ("confidence", "<f4"), ("age", "<i4")], align=True)
+VPH_BALL = np.dtype([("confidence", "<f4"), ("x", "<f4"), ("y", "<f4"), ("pixel_x", "<f4"), ("pixel_y", "<f4")])
+VPH_ROBOT = np.dtype([("confidence", "<f4"), ("robot_id", "<u4"), ("x", "<f4"), ("y", "<f4"), ("orientation", "<f4"), ("pixel_x", "<f4"), ("pixel_y", "<f4"), ("height", "<f4")])
+assert VPH_MATCH.itemsize == 40 and VPH_TRACKED.itemsize == 56 and VPH_BALL.itemsize == 20 and VPH_ROBOT.itemsize == 32
+
+
+def _vph():
+    l = lib()
+    if not getattr(l, "_vph_ready", False):
+        l.vph_detector_create.restype = C.c_void_p
+        l.vph_detector_destroy.argtypes = [C.c_void_p]
+        l.vph_detector_destroy.restype = None
+        l.vph_atan2_fast.restype = C.c_float
+        l.vph_atan2_fast.argtypes = [C.c_float, C.c_float]
+        l._vph_ready = True
+    return l
+
+
+def config_defaults() -> VphConfig:
+    cfg = VphConfig()
+    _vph().vph_config_defaults(C.byref(cfg))
+    return cfg
+
+
+class Detector:
+    """One camera's blob -> SSL_DetectionFrame stage (main.cpp:319-362) behind the flat C binding."""
+
+    def __init__(self, cfg: VphConfig | None = None):
+        self.l = _vph()
+        self.cfg = cfg or config_defaults()
+        self.h = C.c_void_p(self.l.vph_detector_create(C.byref(self.cfg)))
+        if not self.h:
+            raise RuntimeError("vph_detector_create failed")
+
+    def close(self):
+        if self.h:
+            self.l.vph_detector_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def set_geometry(self, calib, calib_size, img_size, field, ball_radius=21.5, max_robot_radius=90.0, lines=(), arcs=(), resampling_factor=1.0):
+        """field = (length, width, boundary, boundary_goal_line or -1, line_thickness)."""
+        c = (C.c_float * 11)(*[float(v) for v in calib])
+        f = (C.c_int32 * 5)(*[int(v) for v in field])
+        ln = np.ascontiguousarray(np.asarray(lines, np.float32).reshape(-1, 4))
+        ar = np.ascontiguousarray(np.asarray(arcs, np.float32).reshape(-1, 5))
+        rc = self.l.vph_detector_set_geometry(self.h, c, int(calib_size[0]), int(calib_size[1]), int(img_size[0]), int(img_size[1]), C.c_float(resampling_factor), f,
+                                              C.c_float(ball_radius), C.c_float(max_robot_radius), self._p(ln), len(ln), self._p(ar), len(ar))
+        if rc != 0:
+            raise RuntimeError(f"vph_detector_set_geometry failed: {rc}")
+
+    def matches_from_cl(self, cl_matches: np.ndarray) -> np.ndarray:
+        """22-byte packed CLMatch records (capi.MATCH_DTYPE) -> VPH_MATCH in field coordinates (main.cpp:303-311)."""
+        cl_matches = np.ascontiguousarray(cl_matches)
+        assert cl_matches.dtype.itemsize == 22
+        out = np.zeros(len(cl_matches), VPH_MATCH)
+        rc = self.l.vph_matches_from_cl(self.h, self._p(cl_matches), len(cl_matches), self._p(out))
+        if rc != 0:
+            raise RuntimeError(f"vph_matches_from_cl failed: {rc}")
+        return out
+
+    def set_tracked(self, cam: int, objs: np.ndarray):
+        objs = np.ascontiguousarray(objs, VPH_TRACKED)
+        assert self.l.vph_detector_set_tracked(self.h, C.c_uint32(cam), self._p(objs), len(objs)) == 0
+
+    def get_tracked(self, cam: int) -> np.ndarray:
+        n = self.l.vph_detector_get_tracked(self.h, C.c_uint32(cam), None, 0)
+        out = np.zeros(n, VPH_TRACKED)
+        self.l.vph_detector_get_tracked(self.h, C.c_uint32(cam), self._p(out), n)
+        return out
+
+    def set_offsets(self, offsets):
+        o = np.ascontiguousarray(offsets, np.float32)
+        assert self.l.vph_detector_set_offsets(self.h, self._p(o), len(o)) == 0
+
+    def colors(self) -> np.ndarray:
+        """(7, 3) int32: orange, field, yellow, blue, green, pink, fieldLineColor."""
+        out = np.zeros((7, 3), np.int32)
+        assert self.l.vph_detector_colors(self.h, self._p(out), 0) == 0
+        return out
+
+    def set_colors(self, colors):
+        c = np.ascontiguousarray(colors, np.int32).reshape(7, 3)
+        assert self.l.vph_detector_colors(self.h, self._p(c), 1) == 0
+
+    def detect(self, matches: np.ndarray, frame_id: int, start_time: float, img_timestamp: float = 0.0) -> dict:
+        matches = np.ascontiguousarray(matches, VPH_MATCH)
+        rc = self.l.vph_detect(self.h, self._p(matches), len(matches), C.c_uint32(frame_id), C.c_double(start_time), C.c_double(img_timestamp))
+        if rc != 0:
+            raise RuntimeError(f"vph_detect failed: {rc}")
+        return self.frame()
+
+    def frame(self) -> dict:
+        hd = VphFrameHeader()
+        assert self.l.vph_frame_header(self.h, C.byref(hd)) == 0
+        balls = np.zeros(hd.n_balls, VPH_BALL)
+        yellow = np.zeros(hd.n_robots_yellow, VPH_ROBOT)
+        blue = np.zeros(hd.n_robots_blue, VPH_ROBOT)
+        offs = np.zeros(hd.n_offsets, np.float32)
+        self.l.vph_frame_balls(self.h, self._p(balls), len(balls))
+        self.l.vph_frame_robots(self.h, 0, self._p(yellow), len(yellow))
+        self.l.vph_frame_robots(self.h, 1, self._p(blue), len(blue))
+        self.l.vph_frame_offsets(self.h, self._p(offs), len(offs))
+        return {"frame_number": hd.frame_number, "camera_id": hd.camera_id, "t_capture": hd.t_capture, "t_sent": hd.t_sent,
+                "t_capture_camera": hd.t_capture_camera if hd.has_t_capture_camera else None, "balls": balls, "robots_yellow": yellow, "robots_blue": blue, "t_offsets": offs}
+
+    def set_t_sent(self, t: float):
+        assert self.l.vph_frame_set_t_sent(self.h, C.c_double(t)) == 0
+
+    def track(self):
+        assert self.l.vph_track(self.h) == 0
+
+    def encode(self) -> bytes:
+        n = -self.l.vph_encode(self.h, None, 0)
+        buf = (C.c_uint8 * max(n, 1))()
+        got = self.l.vph_encode(self.h, buf, n)
+        assert got == n, (got, n)
+        return bytes(buf[:n])
+
+    def decode(self, data: bytes):
+        """Returns (has_detection, source); a detection becomes the current frame."""
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data.ljust(1, b"\0"))
+        src = C.c_int(0)
+        rc = self.l.vph_decode(self.h, buf, len(data), C.byref(src))
+        if rc < 0:
+            raise ValueError("malformed SSL_WrapperPacket")
+        return bool(rc), src.value
+
+
+def atan2_fast(y, x) -> np.float32:
+    return np.float32(_vph().vph_atan2_fast(C.c_float(y), C.c_float(x)))
+
+
+def kmeans(contrast, values, c1, c2):
+    v = np.ascontiguousarray(values, np.int32).reshape(-1, 3)
+    a, b, c = (np.ascontiguousarray(t, np.int32) for t in (contrast, c1, c2))
+    ok = _vph().vph_kmeans(a.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), len(v), b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p))
+    return bool(ok), tuple(int(t) for t in b), tuple(int(t) for t in c)
+
+
+def kdtree_range(points, point, radius):
+    p = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    out = np.zeros(len(p), np.int32)
+    n = _vph().vph_kdtree_range(p.ctypes.data_as(C.c_void_p), len(p), C.c_float(point[0]), C.c_float(point[1]), C.c_float(radius), out.ctypes.data_as(C.c_void_p), len(out))
+    return [int(i) for i in out[:n]]
