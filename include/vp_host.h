@@ -69,6 +69,11 @@ void vph_detector_destroy(VphDetector* d);
 int vph_detector_set_geometry(VphDetector* d, const float calib[11], int calib_w, int calib_h, int img_w, int img_h, float resampling_factor, const int32_t field[5],
 		float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs);
 
+/* The same with the kernel scalars assigned directly instead of derived (fieldScale, extent[0], extent[2] and the
+ * flat size are what the GPU path was launched with); skips the O(image) fieldScale reduction of geometryCheck. */
+int vph_detector_set_geometry_direct(VphDetector* d, const float calib[11], int img_w, int img_h, float field_scale, float off_x, float off_y, int fw, int fh,
+		const int32_t field[5], float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs);
+
 /* main.cpp:303-311: CLMatch (22 bytes packed) -> Match with Perspective::flat2field applied */
 int vph_matches_from_cl(const VphDetector* d, const VpMatch* in, int n, VphMatch* out);
 
@@ -95,6 +100,14 @@ int vph_track(VphDetector* d);
 int vph_encode(const VphDetector* d, uint8_t* buf, int cap);
 /* VisionSocket::parse (udpsocket.cpp:146-154): 1 = packet carried a detection (now the current frame), 0 = none, <0 malformed */
 int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source);
+
+/* One step of `n` independent camera feeds (one detector each, e.g. the frames of one GPU launch group), on `threads` host
+ * threads: per feed the read-back of main.cpp:297-317 (min(max_matches, counter[0]) records of its slice, flat2field), vph_detect,
+ * t_sent, the loop-back of its own packet into its tracker, and the encoded SSL_WrapperPacket into packets + i * packet_cap
+ * (lengths[i] = bytes written, or -needed when packet_cap is too small: nothing written for that feed).
+ * cl_matches = n x max_matches records, counters = n x 3. */
+int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, const int32_t* counters, int max_matches, uint32_t frame_id, double start_time,
+		double img_timestamp, double t_sent, int threads, uint8_t* packets, int packet_cap, int32_t* lengths);
 
 /* building blocks, exported for the unit tests */
 float vph_atan2_fast(float y, float x);                                                              /* hypothesis.cpp:35-58 */

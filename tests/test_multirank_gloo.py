@@ -88,6 +88,72 @@ def _worker(rank, world, port, batch, out_dir):
     open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").close()
 
 
+def _packets(rank, batch, cfg, mm, steps, threads):
+    """The CPU stage of bench.py --detect for one rank: one detector per feed slot, `steps` consecutive steps (colour model and
+    tracker carried along), returns the packets of the last step."""
+    from _vp_pkg import load
+    vp = load()
+    H, f = vp.hostlib, vp.feeds
+    dcfg = H.config_defaults()
+    dets = []
+    for i in range(batch):
+        dcfg.cam_id = rank * batch + i
+        d = H.Detector(dcfg)
+        d.set_geometry_direct(H.nadir_calib(cfg.model()), (cfg.qw, cfg.qh), cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, field=(int(cfg.field_len), int(cfg.field_wid), 300, -1, 10))
+        dets.append(d)
+    counter, matches, _ = _detections(rank, batch, cfg, mm)
+    packets = np.zeros((batch, f.PACKET_CAP), np.uint8)
+    lengths = np.zeros(batch, np.int32)
+    for k in range(1, steps + 1):
+        H.detect_batch(dets, matches, counter, mm, k, k / 70.0, k / 70.0, k / 70.0 + 0.002, threads, packets, lengths)
+    return dets, packets, lengths
+
+
+def _worker_packets(rank, world, port, batch, out_dir):
+    import sys
+    for p in (cases.ROOT, os.path.join(cases.ROOT, "tests"), os.path.join(cases.ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from _vp_pkg import load
+    vp = load()
+    f = vp.feeds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, mm = cfgs.T_MID, 256
+    dets, packets, lengths = _packets(rank, batch, cfg, mm, 2, 2)
+    record = f.pack_packets(torch.from_numpy(lengths), torch.from_numpy(packets), torch.zeros((batch, f.packet_record_bytes()), dtype=torch.uint8))
+    gathered = torch.zeros((world, batch, f.packet_record_bytes()), dtype=torch.uint8)
+    f.gather_records(record, gathered, dist)
+    allp = f.unpack_packets(gathered)
+    ok = True
+    probe = vp.hostlib.Detector()
+    for r in range(world):
+        _, pk, ln = _packets(r, batch, cfg, mm, 2, 1)  # recomputed single-threaded: thread count must not change a byte
+        for i in range(batch):
+            ok &= allp[r][i] == pk[i, : ln[i]].tobytes() and ln[i] > 0
+            has, src = probe.decode(allp[r][i])
+            fr = probe.frame()
+            ok &= has and src == 3 and fr["camera_id"] == r * batch + i and fr["frame_number"] == 2
+            # the rendered scene of T_MID: robots 0..4 with alternating teams, three balls (one feed also reports a field-line crossing as a ball)
+            ok &= sorted(int(b["robot_id"]) for b in fr["robots_yellow"]) == [0, 2, 4] and sorted(int(b["robot_id"]) for b in fr["robots_blue"]) == [1, 3] and len(fr["balls"]) in (3, 4)
+    # second step ran on tracked objects: every detector carries tracks of age 2
+    for i, d in enumerate(dets):
+        tr = d.get_tracked(rank * batch + i)
+        ok &= len(tr) in (8, 9) and int(tr["age"].min()) == 2
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"rank{rank}.ok" if ok else f"rank{rank}.bad"), "w").close()
+
+
+def test_two_ranks_gather_encoded_detection_frames(tmp_path):
+    """BASELINE config 4 on CPU: per rank a set of feeds, each with its own detector (main.cpp:319-370 on host threads), the
+    encoded SSL_WrapperPackets all-gathered with equal counts; every rank ends up with every feed's packet."""
+    world, batch = 2, 2
+    mp.spawn(_worker_packets, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["rank0.ok", "rank1.ok"]
+
+
 def test_two_ranks_gather_detection_records(tmp_path):
     world, batch = 2, 2
     mp.spawn(_worker, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)

@@ -51,3 +51,34 @@ def gather_records(record: torch.Tensor, gathered: torch.Tensor, dist, async_op:
     # flattened views: (world * B, bytes) <- (B, bytes); the gloo backend insists on the concatenated shape, RCCL accepts it too
     work = dist.all_gather_into_tensor(gathered.view(-1, gathered.shape[-1]), record, async_op=async_op)
     return work if async_op else gathered
+
+
+# ---- encoded detection frames (SSL_WrapperPacket bytes per feed, BASELINE config 4) -------------------------------------------
+PACKET_CAP = 4092  # bytes per feed and step: 16 robots x 45 B + 8 balls x 27 B + header is < 1 KB; a UDP datagram of the reference is < 64 KB
+
+
+def packet_record_bytes(cap: int = PACKET_CAP) -> int:
+    return 4 + cap  # int32 length + payload
+
+
+def pack_packets(lengths: torch.Tensor, packets: torch.Tensor, record: torch.Tensor) -> torch.Tensor:
+    """lengths (B,) int32, packets (B, cap) uint8 -> record (B, 4 + cap) uint8, in place."""
+    b = lengths.shape[0]
+    record[:, 0:4] = lengths.contiguous().view(torch.uint8).view(b, 4)
+    record[:, 4:] = packets
+    return record
+
+
+def unpack_packets(gathered: torch.Tensor):
+    """gathered (world, B, 4 + cap) uint8 -> list (per rank) of lists (per feed) of bytes: the SSL_WrapperPacket each feed emitted."""
+    g = gathered.cpu()
+    w, b, _ = g.shape
+    lengths = g[:, :, 0:4].contiguous().view(torch.int32).view(w, b)
+    out = []
+    for r in range(w):
+        row = []
+        for i in range(b):
+            n = int(lengths[r, i])
+            row.append(bytes(g[r, i, 4:4 + n].numpy().tobytes()) if n > 0 else b"")
+        out.append(row)
+    return out

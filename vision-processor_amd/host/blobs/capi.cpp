@@ -1,6 +1,8 @@
 // Flat C binding of the blob -> detection stage (include/vp_host.h).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 #include "detection.h"
 #include "vp_host.h"
@@ -13,6 +15,50 @@ struct VphDetector {
 namespace {
 
 vp::Vec3i v3(const int32_t* c) { return {c[0], c[1], c[2]}; }
+
+vp::FieldSize fieldFrom(const int32_t field[5], float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs) {
+	vp::FieldSize f;
+	f.field_length = field[0];
+	f.field_width = field[1];
+	f.boundary_width = field[2];
+	f.has_boundary_width_goal_line = field[3] >= 0;
+	f.boundary_width_goal_line = field[3] >= 0 ? field[3] : 0;
+	f.line_thickness = field[4];
+	f.ball_radius = ball_radius;
+	f.max_robot_radius = max_robot_radius;
+	for(int i = 0; i < n_lines; i++) f.field_lines.push_back({{lines[4 * i], lines[4 * i + 1]}, {lines[4 * i + 2], lines[4 * i + 3]}});
+	for(int i = 0; i < n_arcs; i++) f.field_arcs.push_back({{arcs[5 * i], arcs[5 * i + 1]}, arcs[5 * i + 2], arcs[5 * i + 3], arcs[5 * i + 4]});
+	return f;
+}
+
+vp::CameraCalibration calibFrom(const float calib[11], int cam_id, int w, int h) {
+	vp::CameraCalibration c;
+	c.camera_id = (uint32_t)cam_id;
+	c.focal_length = calib[0];
+	c.principal_point_x = calib[1];
+	c.principal_point_y = calib[2];
+	c.distortion = calib[3];
+	c.q0 = calib[4];
+	c.q1 = calib[5];
+	c.q2 = calib[6];
+	c.q3 = calib[7];
+	c.tx = calib[8];
+	c.ty = calib[9];
+	c.tz = calib[10];
+	c.pixel_image_width = (uint32_t)w;
+	c.pixel_image_height = (uint32_t)h;
+	return c;
+}
+
+std::vector<vp::Match> matchesFromCl(const vp::Perspective& p, const VpMatch* in, int n) { // main.cpp:303-311
+	std::vector<vp::Match> ms;
+	ms.reserve((size_t)n);
+	for(int i = 0; i < n; i++) {
+		const VpMatch& m = in[i];
+		ms.push_back({p.flat2field({m.x, m.y}), {m.color[0], m.color[1], m.color[2]}, {m.center[0], m.center[1], m.center[2]}, m.circ, m.score});
+	}
+	return ms;
+}
 void put3(int32_t* o, const vp::Vec3i& c) {
 	o[0] = c.x;
 	o[1] = c.y;
@@ -77,36 +123,32 @@ void vph_detector_destroy(VphDetector* d) { delete d; }
 int vph_detector_set_geometry(VphDetector* d, const float calib[11], int calib_w, int calib_h, int img_w, int img_h, float resampling_factor, const int32_t field[5],
 		float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs) {
 	if(!d || !calib || !field || img_w <= 1 || img_h <= 1 || calib_w <= 0 || calib_h <= 0 || n_lines < 0 || n_arcs < 0 || (n_lines && !lines) || (n_arcs && !arcs)) return VP_ERR_INVALID;
-	vp::FieldSize f;
-	f.field_length = field[0];
-	f.field_width = field[1];
-	f.boundary_width = field[2];
-	f.has_boundary_width_goal_line = field[3] >= 0;
-	f.boundary_width_goal_line = field[3] >= 0 ? field[3] : 0;
-	f.line_thickness = field[4];
-	f.ball_radius = ball_radius;
-	f.max_robot_radius = max_robot_radius;
-	for(int i = 0; i < n_lines; i++) f.field_lines.push_back({{lines[4 * i], lines[4 * i + 1]}, {lines[4 * i + 2], lines[4 * i + 3]}});
-	for(int i = 0; i < n_arcs; i++) f.field_arcs.push_back({{arcs[5 * i], arcs[5 * i + 1]}, arcs[5 * i + 2], arcs[5 * i + 3], arcs[5 * i + 4]});
-	vp::CameraCalibration c;
-	c.camera_id = (uint32_t)d->r.camId;
-	c.focal_length = calib[0];
-	c.principal_point_x = calib[1];
-	c.principal_point_y = calib[2];
-	c.distortion = calib[3];
-	c.q0 = calib[4];
-	c.q1 = calib[5];
-	c.q2 = calib[6];
-	c.q3 = calib[7];
-	c.tx = calib[8];
-	c.ty = calib[9];
-	c.tz = calib[10];
-	c.pixel_image_width = (uint32_t)calib_w;
-	c.pixel_image_height = (uint32_t)calib_h;
+	const vp::FieldSize f = fieldFrom(field, ball_radius, max_robot_radius, lines, n_lines, arcs, n_arcs);
+	const vp::CameraCalibration c = calibFrom(calib, d->r.camId, calib_w, calib_h);
 	d->r.perspective->setGeometry(f, &c, 1);
 	d->r.perspective->geometryCheck(img_w, img_h, d->r.maxBotHeight, resampling_factor);
 	d->r.ballRadius = ball_radius; // udpsocket.cpp:123-124
 	return d->r.perspective->geometryVersion ? VP_OK : VP_ERR_INVALID;
+}
+
+int vph_detector_set_geometry_direct(VphDetector* d, const float calib[11], int img_w, int img_h, float field_scale, float off_x, float off_y, int fw, int fh,
+		const int32_t field[5], float ball_radius, float max_robot_radius, const float* lines, int n_lines, const float* arcs, int n_arcs) {
+	if(!d || !calib || !field || img_w <= 1 || img_h <= 1 || !(field_scale > 0.f) || fw <= 0 || fh <= 0 || n_lines < 0 || n_arcs < 0 || (n_lines && !lines) || (n_arcs && !arcs))
+		return VP_ERR_INVALID;
+	vp::Perspective& p = *d->r.perspective;
+	p.field = fieldFrom(field, ball_radius, max_robot_radius, lines, n_lines, arcs, n_arcs);
+	p.model = vp::CameraModel(calibFrom(calib, d->r.camId, img_w, img_h));
+	p.minBlobRadius = std::min({vp::CENTER_BLOB_RADIUS, vp::SIDE_BLOB_RADIUS, ball_radius}); // Perspective.cpp:69-70
+	p.maxBlobRadius = std::max({vp::CENTER_BLOB_RADIUS, vp::SIDE_BLOB_RADIUS, ball_radius});
+	p.fieldScale = field_scale;
+	p.visibleFieldExtent[0] = off_x;
+	p.visibleFieldExtent[1] = off_x + field_scale * (float)fw;
+	p.visibleFieldExtent[2] = off_y;
+	p.visibleFieldExtent[3] = off_y + field_scale * (float)fh;
+	p.reprojectedFieldSize = {fw, fh};
+	p.geometryVersion = 1;
+	d->r.ballRadius = ball_radius;
+	return VP_OK;
 }
 
 int vph_matches_from_cl(const VphDetector* d, const VpMatch* in, int n, VphMatch* out) {
@@ -233,6 +275,37 @@ int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source) {
 	if(source) *source = src;
 	if(has) d->frame = f;
 	return has ? 1 : 0;
+}
+
+int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, const int32_t* counters, int max_matches, uint32_t frame_id, double start_time,
+		double img_timestamp, double t_sent, int threads, uint8_t* packets, int packet_cap, int32_t* lengths) {
+	if(n < 0 || max_matches < 0 || packet_cap < 0 || (n && (!ds || !cl_matches || !counters || !packets || !lengths))) return VP_ERR_INVALID;
+	for(int i = 0; i < n; i++)
+		if(!ds[i] || !ds[i]->r.perspective->geometryVersion) return VP_ERR_INVALID;
+	std::atomic<int> next{0};
+	auto work = [&]() {
+		for(int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+			VphDetector& d = *ds[i];
+			const int amount = std::max(0, std::min(max_matches, counters[3 * i])); // main.cpp:301
+			std::vector<vp::Match> ms = matchesFromCl(*d.r.perspective, cl_matches + (size_t)i * max_matches, amount);
+			d.frame = vp::detectFrame(d.r, ms, frame_id, start_time, img_timestamp);
+			d.frame.t_sent = t_sent;
+			const std::vector<uint8_t> bytes = vp::encodeWrapperPacket(d.frame);
+			vp::detectionTracking(d.r, d.frame); // the feed's own packet comes back through the multicast group (udpsocket.cpp:146-154)
+			if((int)bytes.size() > packet_cap) {
+				lengths[i] = -(int32_t)bytes.size();
+				continue;
+			}
+			std::memcpy(packets + (size_t)i * packet_cap, bytes.data(), bytes.size());
+			lengths[i] = (int32_t)bytes.size();
+		}
+	};
+	const int nt = std::max(1, std::min(threads, n));
+	std::vector<std::thread> pool;
+	for(int t = 1; t < nt; t++) pool.emplace_back(work);
+	work();
+	for(std::thread& t : pool) t.join();
+	return VP_OK;
 }
 
 float vph_atan2_fast(float y, float x) { return vp::atan2_fast(y, x); }

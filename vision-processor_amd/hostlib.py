@@ -139,6 +139,17 @@ class Detector:
         if rc != 0:
             raise RuntimeError(f"vph_detector_set_geometry failed: {rc}")
 
+    def set_geometry_direct(self, calib, img_size, field_scale, off_x, off_y, fw, fh, field=(9000, 6000, 300, -1, 0), ball_radius=21.5, max_robot_radius=90.0, lines=(), arcs=()):
+        """Kernel scalars assigned as the GPU path was launched with instead of derived by geometryCheck."""
+        c = (C.c_float * 11)(*[float(v) for v in calib])
+        f = (C.c_int32 * 5)(*[int(v) for v in field])
+        ln = np.ascontiguousarray(np.asarray(lines, np.float32).reshape(-1, 4))
+        ar = np.ascontiguousarray(np.asarray(arcs, np.float32).reshape(-1, 5))
+        rc = self.l.vph_detector_set_geometry_direct(self.h, c, int(img_size[0]), int(img_size[1]), C.c_float(field_scale), C.c_float(off_x), C.c_float(off_y), int(fw), int(fh), f,
+                                                     C.c_float(ball_radius), C.c_float(max_robot_radius), self._p(ln), len(ln), self._p(ar), len(ar))
+        if rc != 0:
+            raise RuntimeError(f"vph_detector_set_geometry_direct failed: {rc}")
+
     def matches_from_cl(self, cl_matches: np.ndarray) -> np.ndarray:
         """22-byte packed CLMatch records (capi.MATCH_DTYPE) -> VPH_MATCH in field coordinates (main.cpp:303-311)."""
         cl_matches = np.ascontiguousarray(cl_matches)
@@ -233,3 +244,26 @@ def kdtree_range(points, point, radius):
     out = np.zeros(len(p), np.int32)
     n = _vph().vph_kdtree_range(p.ctypes.data_as(C.c_void_p), len(p), C.c_float(point[0]), C.c_float(point[1]), C.c_float(radius), out.ctypes.data_as(C.c_void_p), len(out))
     return [int(i) for i in out[:n]]
+
+
+def nadir_calib(model: VpCameraModel):
+    """The 11 calibration floats of a nadir camera described by a VpCameraModel (vp_synth_camera): q = (x -1, y 0, z 0, w 0),
+    t = R (-pos) = (-cx, cy, cz) for R = diag(1, -1, -1)."""
+    return (model.f, model.p[0], model.p[1], model.d, -1.0, 0.0, 0.0, 0.0, -model.c[0], model.c[1], model.c[2])
+
+
+def detect_batch(detectors, cl_matches: np.ndarray, counters: np.ndarray, max_matches: int, frame_id: int, start_time: float, img_timestamp: float, t_sent: float,
+                 threads: int, packets: np.ndarray, lengths: np.ndarray):
+    """vph_detect_batch: one step of len(detectors) independent feeds on `threads` host threads (the call releases the GIL).
+    cl_matches: (n, 22 * max_matches) uint8 (or a structured 22-byte array), counters (n, 3) int32; packets (n, cap) uint8 and
+    lengths (n,) int32 are filled in place."""
+    n = len(detectors)
+    assert cl_matches.flags.c_contiguous and counters.flags.c_contiguous and packets.flags.c_contiguous and lengths.flags.c_contiguous
+    assert cl_matches.nbytes >= n * 22 * max_matches and counters.dtype == np.int32 and counters.size >= 3 * n
+    assert packets.dtype == np.uint8 and packets.shape[0] >= n and lengths.dtype == np.int32 and lengths.size >= n
+    hs = (C.c_void_p * n)(*[d.h for d in detectors])
+    rc = _vph().vph_detect_batch(hs, n, cl_matches.ctypes.data_as(C.c_void_p), counters.ctypes.data_as(C.c_void_p), int(max_matches), C.c_uint32(frame_id),
+                                 C.c_double(start_time), C.c_double(img_timestamp), C.c_double(t_sent), int(threads), packets.ctypes.data_as(C.c_void_p),
+                                 int(packets.shape[1]), lengths.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"vph_detect_batch failed: {rc}")
