@@ -173,6 +173,9 @@ def main():
 
     det = None
     if args.detect:
+        # host tensor copies must not wake an OpenMP team sized for every visible CPU (256 on a GPU box with a 16-core quota: the
+        # spinning team eats the quota the detector threads need -- measured 40 ms per step instead of 3)
+        torch.set_num_threads(1)
         hostlib = vp.hostlib
         dcfg = hostlib.config_defaults()
         det = {"done": 0, "threads": args.detect_threads or (host_cores() if world == 1 else max(1, min(16, len(os.sched_getaffinity(0)) // world))), "detectors": [], "ev": [torch.cuda.Event() for _ in range(2)],
@@ -197,7 +200,7 @@ def main():
         if pending[p] is not None:
             pending[p].wait()
             pending[p] = None
-        feeds.pack_packets(det["hl"], det["hp"], det["hrec"][p])
+        feeds.pack_packets(det["hl"], det["hp"], det["hrec"][p])  # single-threaded host copy (torch.set_num_threads(1) above)
         det["drec"][p].copy_(det["hrec"][p], non_blocking=True)
         if world > 1:
             pending[p] = feeds.gather_records(det["drec"][p], det["gath"][p], dist, async_op=True)
