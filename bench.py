@@ -138,9 +138,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # VP_BENCH_FORCE_DIST=1 (tools only): initialise RCCL and run the per-step gather even at world size 1, so that the collective
+    # path (backend "nccl" = RCCL, uint8 all_gather_into_tensor on the launch stream's tensors) can be exercised on a one-GPU box
+    force_dist = os.environ.get("VP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -167,7 +171,7 @@ def main():
     matches = torch.zeros((B, 22 * mm), dtype=torch.uint8, device="cuda")
     idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
     counter = torch.zeros((B, 3), dtype=torch.int32, device="cuda")
-    gathered = [torch.empty((world, B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world, B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if dist else None
     pending = [None, None]
     step_no = [0]
 
@@ -184,7 +188,7 @@ def main():
                "hp": torch.zeros((B, feeds.PACKET_CAP), dtype=torch.uint8), "hl": torch.zeros((B,), dtype=torch.int32),
                "hrec": [torch.zeros((B, feeds.packet_record_bytes()), dtype=torch.uint8).pin_memory() for _ in range(2)],
                "drec": [torch.zeros((B, feeds.packet_record_bytes()), dtype=torch.uint8, device="cuda") for _ in range(2)],
-               "gath": [torch.empty((world, B, feeds.packet_record_bytes()), dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else None}
+               "gath": [torch.empty((world, B, feeds.packet_record_bytes()), dtype=torch.uint8, device="cuda") for _ in range(2)] if dist else None}
         for i in range(B):
             dcfg.cam_id = rank * B + i  # every feed slot is its own camera: own colour model, own tracker
             d = hostlib.Detector(dcfg)
@@ -202,7 +206,7 @@ def main():
             pending[p] = None
         feeds.pack_packets(det["hl"], det["hp"], det["hrec"][p])  # single-threaded host copy (torch.set_num_threads(1) above)
         det["drec"][p].copy_(det["hrec"][p], non_blocking=True)
-        if world > 1:
+        if dist:
             pending[p] = feeds.gather_records(det["drec"][p], det["gath"][p], dist, async_op=True)
 
     def cpu_upto(j):
@@ -222,7 +226,7 @@ def main():
             cpu_upto(k)  # the previous step's blobs (steps are numbered from 1) while the GPU works on this one
             return
         ctx.frame(params, d_raw, B, flat, sat, matches, counter, idx=idx)
-        if world > 1:
+        if dist:
             s = step_no[0] & 1
             step_no[0] += 1
             if pending[s] is not None:
@@ -283,7 +287,7 @@ def main():
             "dtype": "u8/int32 (fp32 for coordinates and scores)", "data": "synthetic",
             "config": {"workload": cfg.name, "frames_per_step_per_gpu": B, "sensor": "2048x1536 RGGB8", "flat": f"{cfg.fw}x{cfg.fh}", "grad_offset": cfg.grad_offset,
                        "circle_radius": cfg.circle_radius, "list_radius": cfg.list_radius, "max_blobs": mm, "sat_variant": args.sat, "list_order": args.order,
-                       "sampler": "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (", RCCL all-gather of detection records per step" if world > 1 else "")},
+                       "sampler": "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (", RCCL all-gather of detection records per step" if dist else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "gradientDot+SAT pass", "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},
             "stage_ms_per_step": {k: round(float(np.mean(v)), 4) for k, v in stage_ms.items()},
@@ -305,11 +309,11 @@ def main():
             out["metric"] = "frames/s at 2048x1536 (hot path + CPU hypothesis stage + SSL_WrapperPacket gather)"
             out["detect"] = {"host_threads": det["threads"], "robots_per_frame": float(np.mean(robots)), "balls_per_frame": float(np.mean(balls)),
                              "packet_bytes": float(np.mean([len(p) for p in mine])), "rendered": {"robots": cfg.n_robots, "balls": cfg.n_balls}}
-            if world > 1:
+            if dist:
                 allp = feeds.unpack_packets(det["gath"][last])
                 out["detect"]["gathered_packets"] = sum(1 for r in allp for p in r if p)
                 assert allp[0] == mine
-            out["config"]["sharding"] = f"{world} x {B} independent feeds" + (", RCCL all-gather of SSL_WrapperPackets per step" if world > 1 else "")
+            out["config"]["sharding"] = f"{world} x {B} independent feeds" + (", RCCL all-gather of SSL_WrapperPackets per step" if dist else "")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         print(json.dumps(out), flush=True)
