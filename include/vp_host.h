@@ -101,6 +101,16 @@ int vph_encode(const VphDetector* d, uint8_t* buf, int cap);
 /* VisionSocket::parse (udpsocket.cpp:146-154): 1 = packet carried a detection (now the current frame), 0 = none, <0 malformed */
 int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source);
 
+/* VisionSocket (udpsocket.h:67-113): attach a datagram socket to the detector.  vph_udp_send emits the current frame's packet to
+ * (ip, port) (a multicast group such as 224.5.23.2:10006, or a unicast address); a receiver thread parses every datagram that
+ * arrives there -- the detector's own included -- and tracks its detections per camera id.  vph_udp_sync waits until at least
+ * `at_least` detection packets have been received since the socket was opened (returns the count, or -1 on timeout) and installs
+ * the socket's tracked objects as the detector's (what main.cpp:86 reads through r.socket->getTrackedObjects()). */
+int vph_udp_open(VphDetector* d, const char* ip, int port);
+int vph_udp_send(VphDetector* d);
+int vph_udp_sync(VphDetector* d, int at_least, int timeout_ms);
+int vph_udp_close(VphDetector* d);
+
 /* One step of `n` independent camera feeds (one detector each, e.g. the frames of one GPU launch group), on `threads` host
  * threads: per feed the read-back of main.cpp:297-317 (min(max_matches, counter[0]) records of its slice, flat2field), vph_detect,
  * t_sent, the loop-back of its own packet into its tracker, and the encoded SSL_WrapperPacket into packets + i * packet_cap

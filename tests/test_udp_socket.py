@@ -1,0 +1,125 @@
+"""VisionSocket (src/udpsocket.cpp:26-113,146-163,204-256) on the loopback interface: the packet of wire.cpp travels through a
+real datagram socket, comes back to its sender (as the multicast group delivers it) and feeds the tracker; a plain Python
+socket -- what python/visionsocket.py opens -- receives the same bytes."""
+import socket
+import struct
+
+import numpy as np
+import pytest
+
+import cases
+import test_detection_stage as S
+
+H = cases.vp.hostlib
+
+
+def _free_udp_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tracked_equal(a, b):
+    return len(a) == len(b) and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+
+
+def test_unicast_loopback_feeds_the_tracker_like_the_direct_path():
+    port = _free_udp_port()
+    a, _ = S.make_pair(S.NADIR, cam_id=4)  # packets over UDP
+    b, _ = S.make_pair(S.NADIR, cam_id=4)  # the same frames, tracker fed directly (vph_track)
+    a.udp_open("127.0.0.1", port)
+    arr0, _, _ = S.scene(91, n_robots=5, n_balls=2, n_clutter=4)
+    try:
+        for f in range(3):
+            arr = arr0.copy()
+            arr["x"] += np.float32(3.0 * f)
+            t = 2.0 + f / 60.0
+            fa, fb = a.detect(arr, f + 1, t, t), b.detect(arr, f + 1, t, t)
+            S.assert_frames_equal(fa, {k: (list(v) if isinstance(v, np.ndarray) and v.dtype.names else v) for k, v in fb.items()})
+            for d in (a, b):
+                d.set_t_sent(t + 0.003)
+            assert a.encode() == b.encode()
+            a.udp_send()
+            assert a.udp_sync(f + 1, 3000) == f + 1  # own packet received, parsed and tracked by the receiver thread
+            b.track()
+            assert _tracked_equal(a.get_tracked(4), b.get_tracked(4)) and len(a.get_tracked(4)) >= 6
+    finally:
+        a.udp_close()
+    assert a.udp_sync(1, 10) < 0  # closed socket: invalid
+
+
+def test_a_plain_python_socket_receives_the_protobuf_packet():
+    """Consumer side as in python/visionsocket.py: a UDP socket bound to the port, bytes parsed with google.protobuf."""
+    W = pytest.importorskip("test_wire_format")
+    port = _free_udp_port()
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    d, _ = S.make_pair(S.NADIR, cam_id=1)
+    group = "224.5.23.2"  # network.vision_ip default (Resources.cpp:113)
+    multicast = True
+    try:
+        rx.bind(("", port))
+        rx.setsockopt(socket.IPPROTO_IP, socket.IP_ADD_MEMBERSHIP, struct.pack("4s4s", socket.inet_aton(group), socket.inet_aton("0.0.0.0")))
+    except OSError:
+        multicast = False
+    if multicast:
+        try:
+            d.udp_open(group, port)
+        except OSError:
+            multicast = False
+    if not multicast:
+        # no multicast route in this sandbox: the consumer takes the port, the producer sends unicast to it (its own bind fails
+        # with a warning, exactly like a second process on the reference's port without the group)
+        rx.close()
+        rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        rx.bind(("127.0.0.1", port))
+        d.udp_open("127.0.0.1", port)
+    rx.settimeout(3.0)
+    arr, _, _ = S.scene(92)
+    fr = d.detect(arr, 9, 5.0, 4.5)
+    d.set_t_sent(5.01)
+    d.udp_send()
+    try:
+        data = None
+        for _ in range(4):
+            try:
+                data, _addr = rx.recvfrom(65535)
+            except socket.timeout:
+                break
+            if data:
+                break
+        if not data and multicast:
+            pytest.skip("multicast group joined but nothing delivered on this host")
+        assert data == d.encode()
+        w = W.Wrapper()
+        w.ParseFromString(data)
+        assert w.source == 3 and w.detection.frame_number == 9 and w.detection.camera_id == 1
+        assert len(w.detection.robots_yellow) == len(fr["robots_yellow"]) and len(w.detection.robots_blue) == len(fr["robots_blue"])
+    finally:
+        d.udp_close()
+        rx.close()
+
+
+def test_foreign_and_malformed_datagrams_are_ignored():
+    port = _free_udp_port()
+    d, _ = S.make_pair(S.NADIR, cam_id=0)
+    d.udp_open("127.0.0.1", port)
+    tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    try:
+        tx.sendto(b"\x0a\x05\x08", ("127.0.0.1", port))        # truncated
+        tx.sendto(b"\x12\x02\x08\x01", ("127.0.0.1", port))    # geometry only
+        tx.sendto(b"garbage-not-protobuf\xff\xff", ("127.0.0.1", port))
+        other = H.Detector()
+        arr, _, _ = S.scene(93)
+        o, _ = S.make_pair(S.NADIR, cam_id=7)
+        o.detect(arr, 1, 1.0)
+        o.set_t_sent(1.001)
+        tx.sendto(o.encode(), ("127.0.0.1", port))             # another camera's detections
+        assert d.udp_sync(1, 3000) == 1                        # only the well-formed detection packet counted
+        assert len(d.get_tracked(7)) >= 6 and len(d.get_tracked(0)) == 0
+        del other
+    finally:
+        tx.close()
+        d.udp_close()

@@ -10,6 +10,7 @@
 struct VphDetector {
 	vp::BlobResources r;
 	vp::DetectionFrame frame;
+	std::unique_ptr<vp::VisionSocket> socket;
 };
 
 namespace {
@@ -305,6 +306,35 @@ int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, c
 	for(int t = 1; t < nt; t++) pool.emplace_back(work);
 	work();
 	for(std::thread& t : pool) t.join();
+	return VP_OK;
+}
+
+int vph_udp_open(VphDetector* d, const char* ip, int port) {
+	if(!d || !ip || port <= 0 || port > 65535) return VP_ERR_INVALID;
+	d->socket = std::make_unique<vp::VisionSocket>(ip, (uint16_t)port, d->r.camId, (float)d->r.defaultBotHeight);
+	if(!d->socket->ok()) {
+		d->socket.reset();
+		return VP_ERR_INVALID;
+	}
+	return VP_OK;
+}
+
+int vph_udp_send(VphDetector* d) {
+	if(!d || !d->socket) return VP_ERR_INVALID;
+	d->socket->send(d->frame);
+	return VP_OK;
+}
+
+int vph_udp_sync(VphDetector* d, int at_least, int timeout_ms) {
+	if(!d || !d->socket) return VP_ERR_INVALID;
+	if(!d->socket->waitForPackets(at_least, timeout_ms)) return -1;
+	d->r.trackedObjects = d->socket->getTrackedObjects();
+	return d->socket->receivedPackets();
+}
+
+int vph_udp_close(VphDetector* d) {
+	if(!d) return VP_ERR_INVALID;
+	d->socket.reset();
 	return VP_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "../CameraModel.h"
@@ -189,5 +190,51 @@ void detectionTracking(BlobResources& r, const DetectionFrame& detection);
 std::vector<uint8_t> encodeWrapperPacket(const DetectionFrame& detection);
 // and back (what VisionSocket::parse needs from a received packet: udpsocket.cpp:146-154); false on malformed input
 bool decodeWrapperPacket(const uint8_t* data, size_t size, DetectionFrame& detection, bool& hasDetection, int& source);
+
+// src/udpsocket.{h,cpp}:26-113 -- the datagram socket the wrapper packets travel on.  UDPSocket opens an IPv4 datagram socket
+// bound to (ip, port) with SO_REUSEADDR / SO_BROADCAST / multicast TTL 32, joins the group when ip is a multicast address, and
+// runs a receiver thread that hands every datagram to parse().  (The reference starts that thread in the base-class constructor,
+// i.e. before the derived vtable exists; here the derived class starts it.)
+class UDPSocket {
+public:
+	UDPSocket(const std::string& ip, uint16_t port);
+	virtual ~UDPSocket();
+	UDPSocket(const UDPSocket&) = delete;
+	UDPSocket& operator=(const UDPSocket&) = delete;
+	bool send(const uint8_t* data, size_t size); // udpsocket.cpp:94-100 without the protobuf serialisation
+	bool ok() const { return socket_ >= 0; }
+
+protected:
+	virtual void parse(const uint8_t* data, int length) = 0;
+	void start(); // call at the end of the most derived constructor
+	void stop();  // call at the start of the most derived destructor
+
+private:
+	void run();
+	int socket_ = -1;
+	unsigned char addr_[16] = {0}; // sockaddr_in
+	struct Impl;
+	Impl* impl = nullptr;
+};
+
+// VisionSocket (udpsocket.h:67-113), the part on this path: send the frame's SSL_WrapperPacket, receive everybody's (including
+// its own, the group loops back) and keep per-camera tracked objects for the next frame's tracked hypotheses.
+class VisionSocket: public UDPSocket {
+public:
+	VisionSocket(const std::string& ip, uint16_t port, int camId, float defaultBotHeight);
+	~VisionSocket() override;
+	void send(const DetectionFrame& detection);                                 // socket->send(wrapper), main.cpp:370
+	std::map<unsigned int, std::vector<TrackingState>> getTrackedObjects();       // udpsocket.cpp:132-137
+	int receivedPackets();                                                        // datagrams that carried a detection
+	bool waitForPackets(int atLeast, int timeoutMs);
+
+protected:
+	void parse(const uint8_t* data, int length) override; // udpsocket.cpp:146-163 (detection part)
+
+private:
+	struct State;
+	State* state;
+	const int camId;
+};
 
 } // namespace vp

@@ -1,0 +1,146 @@
+// The datagram socket of src/udpsocket.cpp:26-113 and the detection half of VisionSocket (:146-163, 204-256), POSIX only.
+// Networking is I/O around the path, kept to what carries the wire format of wire.cpp between camera processes.
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "detection.h"
+
+namespace vp {
+
+struct UDPSocket::Impl {
+	std::thread receiver;
+	std::atomic<bool> closing{false};
+	bool started = false;
+};
+
+UDPSocket::UDPSocket(const std::string& ip, uint16_t port): impl(new Impl()) {
+	static_assert(sizeof(sockaddr_in) <= sizeof(addr_), "addr_ too small");
+	sockaddr_in* in = reinterpret_cast<sockaddr_in*>(addr_);
+	in->sin_family = AF_INET;
+	in->sin_port = htons(port);
+	if(!inet_aton(ip.c_str(), &in->sin_addr)) {
+		fprintf(stderr, "[WARN] Invalid UDP target address %s\n", ip.c_str());
+		return;
+	}
+	socket_ = socket(AF_INET, SOCK_DGRAM, 0);
+	if(socket_ < 0) {
+		fprintf(stderr, "[WARN] Failed to open UDP socket\n");
+		return;
+	}
+	const int yes = 1, ttl = 32;
+	if(setsockopt(socket_, SOL_SOCKET, SO_REUSEADDR, &yes, sizeof(yes)) < 0) fprintf(stderr, "[WARN] Setting SO_REUSEADDR on UDP socket failed\n");
+	if(setsockopt(socket_, SOL_SOCKET, SO_BROADCAST, &yes, sizeof(yes)) < 0) fprintf(stderr, "[WARN] Setting SO_BROADCAST on UDP socket failed\n");
+	if(setsockopt(socket_, IPPROTO_IP, IP_MULTICAST_TTL, &ttl, sizeof(ttl)) < 0) fprintf(stderr, "[WARN] Setting TTL failed\n");
+	if(bind(socket_, reinterpret_cast<const sockaddr*>(in), sizeof(*in))) fprintf(stderr, "[WARN] Could not bind to UDP socket %s:%u\n", ip.c_str(), port);
+	if(IN_MULTICAST(ntohl(in->sin_addr.s_addr))) {
+		ip_mreq mreq = {};
+		mreq.imr_multiaddr = in->sin_addr;
+		mreq.imr_interface.s_addr = htonl(INADDR_ANY);
+		if(setsockopt(socket_, IPPROTO_IP, IP_ADD_MEMBERSHIP, &mreq, sizeof(mreq)) < 0) fprintf(stderr, "[WARN] Could not join multicast group %s\n", ip.c_str());
+	}
+}
+
+void UDPSocket::start() {
+	if(socket_ < 0 || impl->started) return;
+	impl->started = true;
+	impl->receiver = std::thread(&UDPSocket::run, this);
+}
+
+void UDPSocket::stop() {
+	if(!impl->started) return;
+	impl->closing = true;
+	shutdown(socket_, SHUT_RD);
+	// a datagram to ourselves wakes a receiver that shutdown() did not (unconnected UDP sockets on some kernels)
+	sendto(socket_, "", 0, 0, reinterpret_cast<const sockaddr*>(addr_), sizeof(sockaddr_in));
+	impl->receiver.join();
+	impl->started = false;
+}
+
+UDPSocket::~UDPSocket() {
+	stop();
+	if(socket_ >= 0) ::close(socket_);
+	delete impl;
+}
+
+bool UDPSocket::send(const uint8_t* data, size_t size) {
+	if(socket_ < 0) return false;
+	if(sendto(socket_, data, size, 0, reinterpret_cast<const sockaddr*>(addr_), sizeof(sockaddr_in)) < 0) {
+		fprintf(stderr, "[WARN] UDP Frame send failed: %s\n", strerror(errno));
+		return false;
+	}
+	return true;
+}
+
+void UDPSocket::run() {
+	std::vector<uint8_t> msgbuf(65535);
+	while(true) {
+		const ssize_t bytesRead = read(socket_, msgbuf.data(), msgbuf.size());
+		if(impl->closing) return;
+		if(bytesRead < 0) {
+			fprintf(stderr, "[WARN] UDP Frame recv failed: %s\n", strerror(errno));
+			return;
+		}
+		parse(msgbuf.data(), (int)bytesRead);
+	}
+}
+
+struct VisionSocket::State {
+	std::mutex m;
+	std::condition_variable cv;
+	BlobResources tracker; // only trackedObjects and ballRadius are used (detectionTracking's working set)
+	int received = 0;
+};
+
+VisionSocket::VisionSocket(const std::string& ip, uint16_t port, int camId, float defaultBotHeight): UDPSocket(ip, port), state(new State()), camId(camId) {
+	state->tracker.defaultBotHeight = defaultBotHeight;
+	start();
+}
+
+VisionSocket::~VisionSocket() {
+	stop();
+	delete state;
+}
+
+void VisionSocket::send(const DetectionFrame& detection) {
+	const std::vector<uint8_t> bytes = encodeWrapperPacket(detection);
+	UDPSocket::send(bytes.data(), bytes.size());
+}
+
+void VisionSocket::parse(const uint8_t* data, int length) {
+	DetectionFrame frame;
+	bool hasDetection = false;
+	int source = 0;
+	if(!decodeWrapperPacket(data, (size_t)length, frame, hasDetection, source)) return; // ParseFromArray failure: dropped (udpsocket.cpp:147-148)
+	if(!hasDetection) return;
+	std::lock_guard<std::mutex> lock(state->m);
+	detectionTracking(state->tracker, frame);
+	state->received++;
+	state->cv.notify_all();
+}
+
+std::map<unsigned int, std::vector<TrackingState>> VisionSocket::getTrackedObjects() {
+	std::lock_guard<std::mutex> lock(state->m);
+	return state->tracker.trackedObjects;
+}
+
+int VisionSocket::receivedPackets() {
+	std::lock_guard<std::mutex> lock(state->m);
+	return state->received;
+}
+
+bool VisionSocket::waitForPackets(int atLeast, int timeoutMs) {
+	std::unique_lock<std::mutex> lock(state->m);
+	return state->cv.wait_for(lock, std::chrono::milliseconds(timeoutMs), [&] { return state->received >= atLeast; });
+}
+
+} // namespace vp

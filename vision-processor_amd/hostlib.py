@@ -211,6 +211,21 @@ class Detector:
     def track(self):
         assert self.l.vph_track(self.h) == 0
 
+    def udp_open(self, ip: str, port: int):
+        rc = self.l.vph_udp_open(self.h, ip.encode(), int(port))
+        if rc != 0:
+            raise OSError(f"vph_udp_open({ip}:{port}) failed: {rc}")
+
+    def udp_send(self):
+        assert self.l.vph_udp_send(self.h) == 0
+
+    def udp_sync(self, at_least: int, timeout_ms: int = 2000) -> int:
+        """Waits for `at_least` received detection packets; installs the socket's tracked objects; returns the count (-1 = timeout)."""
+        return int(self.l.vph_udp_sync(self.h, int(at_least), int(timeout_ms)))
+
+    def udp_close(self):
+        self.l.vph_udp_close(self.h)
+
     def encode(self) -> bytes:
         n = -self.l.vph_encode(self.h, None, 0)
         buf = (C.c_uint8 * max(n, 1))()
