@@ -317,6 +317,23 @@ class Ref(_Base):
         n = min(int(cnt[0]), max_matches)
         return m[:n].copy(), idx[:n].copy(), cnt
 
+    def frame_mt(self, raw, layout, qw, qh, model, max_robot_height, field_scale, off_x, off_y, sampler_mode, fw, fh, o, r, R, circ_threshold, min_score, max_matches, threads,
+                 scratch=None):
+        """The whole chain through the reference's compiled kernels with every NDRange spread over `threads` host threads (timing
+        baseline; blob order is the threads').  Returns (matches, counter)."""
+        raw = _c(raw, np.uint8).reshape(-1)
+        if scratch is None:
+            scratch = (np.zeros(4 * qw * qh, np.uint8), np.zeros(4 * fw * fh, np.uint8), np.zeros(fw * fh, np.float32), np.zeros(fw * fh, np.float32), np.zeros(fw * fh, np.float32))
+        planes, flat, fa, fb, fc = scratch
+        m = np.zeros(max(max_matches, 1), MATCH_DTYPE)
+        cnt = np.zeros(3, np.int32)
+        self.lib.ref_set_sampler_mode(int(sampler_mode))
+        rc = self.lib.ref_frame_mt(_u8(raw), int(layout), int(qw), int(qh), C.byref(model), C.c_float(max_robot_height), C.c_float(field_scale), C.c_float(off_x), C.c_float(off_y),
+                                   int(fw), int(fh), int(o), int(r), int(R), C.c_float(circ_threshold), C.c_float(min_score), int(max_matches), int(threads),
+                                   _u8(planes), _u8(flat), _f32(fa), _f32(fb), _f32(fc), m.ctypes.data_as(C.c_void_p), _p(cnt, C.c_int32))
+        assert rc == 0
+        return m[: min(int(cnt[0]), max_matches)].copy(), cnt
+
     def blobscore(self, flat, circ, circ_threshold, R):
         flat = _c(flat, np.uint8)
         circ = _c(circ, np.float32)

@@ -19,12 +19,16 @@
  *     The mode is a process-global switch (ref_set_sampler_mode) recorded with every golden vector.
  *   - write_imageui to 8-bit channels saturates (spec 6.15.15.4); single-channel images return
  *     (x, 0, 0, 1) on read.
- *   - atomic_inc is a plain increment: the NDRange loop here is sequential, so blob order is raster.
+ *   - atomic_inc is an atomic fetch-and-add.  The per-kernel NDRange loops here are sequential, so blob order is raster there;
+ *     ref_frame_mt (timing only) splits every NDRange into row bands over host threads, the way a CPU OpenCL runtime spreads
+ *     work-groups over cores, and its blob order is whatever the threads produce (blobList.cl:87).
  *
  * Built with the same clang as the kernels so ext_vector_type arguments share one ABI.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef int int2 __attribute__((ext_vector_type(2)));
@@ -166,7 +170,7 @@ float4 ocl_native_sqrt(float4 v) {
 float ocl_min(float x, float y) __asm__("_Z3minff");
 float ocl_min(float x, float y) { return y < x ? y : x; }
 int ocl_atomic_inc(volatile int* p) __asm__("_Z10atomic_incPU8CLglobalVi");
-int ocl_atomic_inc(volatile int* p) { int o = *p; *p = o + 1; return o; }
+int ocl_atomic_inc(volatile int* p) { return __atomic_fetch_add((int*)p, 1, __ATOMIC_RELAXED); }
 /* convert_uchar_sat (OpenCL C 6.4.3): saturating; the float overload rounds toward zero, NaN -> 0 */
 unsigned char ocl_convert_uchar_sat_u(unsigned int v) __asm__("_Z17convert_uchar_satj");
 unsigned char ocl_convert_uchar_sat_u(unsigned int v) { return v > 255u ? 255 : (unsigned char)v; }
@@ -298,4 +302,97 @@ void ref_rgba2nv12(unsigned char* rgba, int w, int h, unsigned char* nv12) {
 void ref_f2nv12(float* img, int w, int h, unsigned char* nv12) {
 	RefImage in = mk(w, h, REF_FMT_F32, img);
 	NDRANGE_2D(w, h, __clang_ocl_kern_imp_f2nv12(&in, nv12));
+}
+
+
+/* ---- whole frame on several host threads (bench.py cpu_baseline kind "reference") ---------------------------------------------
+ * The seven launches of Resources.cpp:142,159-163 and main.cpp:289, each NDRange cut into contiguous bands (rows of a 2-D range,
+ * work-items of a 1-D range), one band per thread, a join between launches (the reference chains them by events).  Every
+ * work-item still runs the reference's own compiled kernel body. */
+typedef struct {
+	int stage, layout;
+	long lo, hi, w, h;
+	const unsigned char* raw;
+	RefImage *c0, *c1, *c2, *c3, *flat, *f0, *f1;
+	const RefCameraModel* m;
+	float maxRobotHeight, fieldScale, offX, offY, circThreshold, minScore;
+	int offset, radius, listRadius, maxMatches;
+	void* matches;
+	int* counter;
+} RefJob;
+
+static void* ref_job_run(void* arg) {
+	const RefJob* j = (const RefJob*)arg;
+	if(j->stage == 3 || j->stage == 4) { /* 1-D ranges: satHorizontal over rows, satVertical over columns */
+		g_gsize[0] = j->stage == 3 ? j->h : j->w; g_gsize[1] = 1; g_gid[1] = 0;
+		for(long i = j->lo; i < j->hi; i++) {
+			g_gid[0] = i;
+			if(j->stage == 3) __clang_ocl_kern_imp_sat_horizontal(j->f0, j->f1);
+			else __clang_ocl_kern_imp_sat_vertical(j->f0, j->f1);
+		}
+		return NULL;
+	}
+	g_gsize[0] = j->w; g_gsize[1] = j->h;
+	for(long y = j->lo; y < j->hi; y++) for(long x = 0; x < j->w; x++) {
+		g_gid[0] = x; g_gid[1] = y;
+		switch(j->stage) {
+		case 0:
+			if(j->layout == 0) __clang_ocl_kern_imp_raw2quad_RGGB(j->raw, j->c0, j->c1, j->c2, j->c3);
+			else if(j->layout == 1) __clang_ocl_kern_imp_raw2quad_GRBG(j->raw, j->c0, j->c1, j->c2, j->c3);
+			else __clang_ocl_kern_imp_raw2quad_BGR(j->raw, j->c0, j->c1, j->c2, j->c3);
+			break;
+		case 1:
+			if(j->layout == 0) __clang_ocl_kern_imp_resampling_RGGB(j->c0, j->c1, j->c2, j->c3, j->flat, *j->m, j->maxRobotHeight, j->fieldScale, j->offX, j->offY);
+			else if(j->layout == 1) __clang_ocl_kern_imp_resampling_GRBG(j->c0, j->c1, j->c2, j->c3, j->flat, *j->m, j->maxRobotHeight, j->fieldScale, j->offX, j->offY);
+			else __clang_ocl_kern_imp_resampling_BGR(j->c0, j->c1, j->c2, j->c3, j->flat, *j->m, j->maxRobotHeight, j->fieldScale, j->offX, j->offY);
+			break;
+		case 2: __clang_ocl_kern_imp_gradient_dotproduct(j->flat, j->f0, j->offset); break;
+		case 5: __clang_ocl_kern_imp_circle(j->f0, j->f1, j->radius); break;
+		case 6: __clang_ocl_kern_imp_matches(j->flat, j->f0, j->matches, j->counter, j->circThreshold, j->minScore, j->listRadius, j->maxMatches); break;
+		}
+	}
+	return NULL;
+}
+
+static void ref_launch(RefJob base, long n, int threads) {
+	if(threads < 1) threads = 1;
+	if(threads > 256) threads = 256;
+	pthread_t tid[256];
+	RefJob jobs[256];
+	int started = 0;
+	for(int t = 0; t < threads; t++) {
+		jobs[t] = base;
+		jobs[t].lo = n * t / threads;
+		jobs[t].hi = n * (t + 1) / threads;
+		if(jobs[t].lo == jobs[t].hi) continue;
+		if(t == threads - 1 || pthread_create(&tid[started], NULL, ref_job_run, &jobs[t]) != 0) ref_job_run(&jobs[t]);
+		else started++;
+	}
+	for(int t = 0; t < started; t++) pthread_join(tid[t], NULL);
+}
+
+/* scratch: caller-provided, 4*qw*qh bytes of planes + 4*fw*fh bytes flat + 3 * 4*fw*fh bytes of float images.  counter[3] is zeroed
+ * here (main.cpp:283-288).  Returns 0, or -1 when a buffer is missing. */
+int ref_frame_mt(const unsigned char* raw, int layout, int qw, int qh, const RefCameraModel* m, float maxRobotHeight, float fieldScale, float offX, float offY,
+		int fw, int fh, int offset, int circleRadius, int listRadius, float circThreshold, float minScore, int maxMatches, int threads,
+		unsigned char* planes, unsigned char* flat, float* fa, float* fb, float* fc, void* matches, int* counter) {
+	if(!raw || !m || !planes || !flat || !fa || !fb || !fc || !matches || !counter) return -1;
+	const size_t pn = (size_t)qw * qh;
+	RefImage c0 = mk(qw, qh, REF_FMT_U8, planes), c1 = mk(qw, qh, REF_FMT_U8, planes + pn), c2 = mk(qw, qh, REF_FMT_U8, planes + 2 * pn), c3 = mk(qw, qh, REF_FMT_U8, planes + 3 * pn);
+	RefImage fl = mk(fw, fh, REF_FMT_RGBA8, flat), ia = mk(fw, fh, REF_FMT_F32, fa), ib = mk(fw, fh, REF_FMT_F32, fb), ic = mk(fw, fh, REF_FMT_F32, fc);
+	RefJob j;
+	memset(&j, 0, sizeof(j));
+	j.layout = layout; j.raw = raw; j.c0 = &c0; j.c1 = &c1; j.c2 = &c2; j.c3 = &c3; j.flat = &fl; j.m = m;
+	j.maxRobotHeight = maxRobotHeight; j.fieldScale = fieldScale; j.offX = offX; j.offY = offY;
+	j.offset = offset; j.radius = circleRadius; j.listRadius = listRadius; j.circThreshold = circThreshold; j.minScore = minScore; j.maxMatches = maxMatches;
+	j.matches = matches; j.counter = counter;
+	counter[0] = counter[1] = counter[2] = 0;
+	j.stage = 0; j.w = qw; j.h = qh; ref_launch(j, qh, threads);                       /* raw2quad        (Resources.cpp:142) */
+	j.stage = 1; j.w = fw; j.h = fh; ref_launch(j, fh, threads);                       /* resampling      (:159) */
+	j.stage = 2; j.f0 = &ia; ref_launch(j, fh, threads);                               /* gradientDot     (:160) -> fa */
+	j.stage = 3; j.f0 = &ia; j.f1 = &ib; ref_launch(j, fh, threads);                   /* satHorizontal   (:161) fa -> fb, one work-item per row */
+	j.stage = 4; j.f0 = &ib; j.f1 = &ic; ref_launch(j, fw, threads);                   /* satVertical     (:162) fb -> fc, one work-item per column */
+	j.stage = 5; j.f0 = &ic; j.f1 = &ia; ref_launch(j, fh, threads);                   /* circle          (:163) fc -> fa */
+	j.stage = 6; j.f0 = &ia; ref_launch(j, fh, threads);                               /* matches         (main.cpp:289) */
+	return 0;
 }

@@ -75,3 +75,25 @@ def test_colour_kernels_port_equals_reference(port, ref, shape):
     f = (rng.standard_normal((qh, qw)) * 200).astype(np.float32)
     f[0, :6] = [np.nan, np.inf, -np.inf, 127.999, -127.0, 128.0]
     assert np.array_equal(port.f2nv12(f), ref.f2nv12(f))
+
+
+@pytest.mark.parametrize("cfg", [cases.cfgs.T_MID, cases.cfgs.T_BGR, cases.cfgs.T_RAGGED], ids=lambda c: c.name)
+def test_threaded_reference_frame_equals_the_sequential_launches(ref, cfg):
+    """ref_frame_mt (bench.py's cpu_baseline kind "reference": every NDRange in row bands over host threads) produces the same
+    blob records and counters as the per-kernel sequential launches; only the append order may differ (blobList.cl:87)."""
+    import oracle as O
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    raw = cfg.synth(5)
+    planes = ref.raw2quad(raw, cfg.layout, cfg.qw, cfg.qh)
+    flat = ref.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh)
+    bc = ref.blobcenter(ref.sat_vertical(ref.sat_horizontal(ref.graddot(flat, cfg.grad_offset))), cfg.circle_radius)
+    m1, _, c1 = ref.bloblist(flat, bc, cfg.circ_threshold, cfg.min_score, cfg.list_radius, cfg.max_matches)
+    assert len(m1) > 3
+    for threads in (1, 3, 8):
+        m2, c2 = ref.frame_mt(raw, cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh, cfg.grad_offset,
+                              cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, cfg.max_matches, threads)
+        assert np.array_equal(c1, c2)
+        recs = lambda m: sorted(m.tobytes()[k * 22:(k + 1) * 22] for k in range(len(m)))
+        assert recs(m1) == recs(m2)
+        if threads == 1:
+            assert m1.tobytes() == m2.tobytes()  # one thread = raster order
