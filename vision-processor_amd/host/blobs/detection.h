@@ -12,6 +12,7 @@
 // restatement (oracle/detect_oracle.py), which pins the two against each other and nothing more.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -60,7 +61,8 @@ private:
 	void search(int n, std::vector<Match*>& values, const Vec2f& point, float radius) const;
 };
 
-bool kMeans(const Vec3i& contrast, const std::vector<Vec3i>& values, Vec3i& c1, Vec3i& c2); // blobs/kmeans.cpp:19-90
+bool kMeans(const Vec3i& contrast, const Vec3i* values, size_t n, Vec3i& c1, Vec3i& c2);      // blobs/kmeans.cpp:19-90
+inline bool kMeans(const Vec3i& contrast, const std::vector<Vec3i>& values, Vec3i& c1, Vec3i& c2) { return kMeans(contrast, values.data(), values.size(), c1, c2); }
 float atan2_fast(float y, float x);                                                            // blobs/hypothesis.cpp:21-58
 
 // pattern.h:18-61

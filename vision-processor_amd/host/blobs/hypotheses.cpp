@@ -52,7 +52,7 @@ void calcColorScore(const BlobResources& r, BallHypothesis& ball) { // :82-94
 	ball.score *= 1 - (float)orange / (float)falseOrange;
 }
 
-void calcPos(BotHypothesis& bot) { // :155-191
+Rot2 calcPos(BotHypothesis& bot) { // :155-191; returns Rotation2Df(orientation), which calcOffsetScore builds again in the reference (same value)
 	float oSin = 0, oCos = 0;
 	for(int a = 0; a < 5; a++) {
 		if(bot.blobs[a] == nullptr) continue;
@@ -64,7 +64,7 @@ void calcPos(BotHypothesis& bot) { // :155-191
 			oCos += cosf(angleDelta);
 		}
 	}
-	if(bot.blobAmount < 1) return;
+	if(bot.blobAmount < 1) return Rot2(bot.orientation);
 	if(bot.blobAmount > 1) bot.orientation = atan2_fast(oSin, oCos);
 
 	const Rot2 rotation(bot.orientation);
@@ -77,10 +77,10 @@ void calcPos(BotHypothesis& bot) { // :155-191
 	}
 	bot.pos.x /= (float)bot.blobAmount;
 	bot.pos.y /= (float)bot.blobAmount;
+	return rotation;
 }
 
-void calcOffsetScore(BotHypothesis& bot) { // :193-205
-	const Rot2 rotation(bot.orientation);
+void calcOffsetScore(BotHypothesis& bot, const Rot2& rotation) { // :193-205
 	for(int i = 0; i < 5; i++) {
 		const Match* blob = bot.blobs[i];
 		if(blob == nullptr) continue;
@@ -98,14 +98,15 @@ BotHypothesis makeBase(const Match* a, const Match* b, const Match* c, const Mat
 		bot.blobs[i] = in[i];
 		if(in[i] != nullptr) bot.blobAmount++;
 	}
-	calcPos(bot);
-	calcOffsetScore(bot);
+	const Rot2 rotation = calcPos(bot);
+	calcOffsetScore(bot, rotation);
 	return bot;
 }
 
 void calcBotId(const BlobResources& r, BotHypothesis& bot) { // :216-228
 	Vec3i green = r.green, pink = r.pink;
-	kMeans(bot.blobs[0]->color, {bot.blobs[1]->color, bot.blobs[2]->color, bot.blobs[3]->color, bot.blobs[4]->color}, green, pink);
+	const Vec3i sides[4] = {bot.blobs[1]->color, bot.blobs[2]->color, bot.blobs[3]->color, bot.blobs[4]->color};
+	kMeans(bot.blobs[0]->color, sides, 4, green, pink);
 	auto isGreen = [&](int i) { return sqDiff(bot.blobs[i]->color, green) < sqDiff(bot.blobs[i]->color, pink) ? 1 : 0; };
 	const int team = sqDiff(bot.blobs[0]->color, r.blue) < sqDiff(bot.blobs[0]->color, r.yellow) ? 16 : 0;
 	bot.botId = team + patternLUT[(isGreen(1) << 3) + (isGreen(2) << 2) + (isGreen(3) << 1) + isGreen(4)];

@@ -43,20 +43,20 @@ void KDTree::rangeSearch(std::vector<Match*>& values, const Vec2f& point, const 
 	if(!nodes.empty()) search(0, values, point, radius);
 }
 
-bool kMeans(const Vec3i& contrast, const std::vector<Vec3i>& values, Vec3i& c1, Vec3i& c2) {
-	if(values.size() < 2) return false; // kmeans.cpp:20-21
+bool kMeans(const Vec3i& contrast, const Vec3i* values, const size_t n, Vec3i& c1, Vec3i& c2) {
+	if(n < 2) return false; // kmeans.cpp:20-21
 
 	float inGroupDiff = INFINITY, outGroupDiff = INFINITY; // :23-33
-	for(size_t i = 0; i < values.size(); i++) {
+	for(size_t i = 0; i < n; i++) {
 		outGroupDiff = std::min(outGroupDiff, (float)sqDiff(values[i], contrast));
-		for(size_t j = i + 1; j < values.size(); j++) inGroupDiff = std::min(inGroupDiff, (float)sqDiff(values[j], values[i]));
+		for(size_t j = i + 1; j < n; j++) inGroupDiff = std::min(inGroupDiff, (float)sqDiff(values[j], values[i]));
 	}
 	if(inGroupDiff > outGroupDiff) return false; // :35-36
 
 	const Vec3i c1backup = c1, c2backup = c2;
 	auto nearest = [&](const Vec3i& c) { // std::min_element: the first of equally near values (:43-44)
 		size_t best = 0;
-		for(size_t i = 1; i < values.size(); i++)
+		for(size_t i = 1; i < n; i++)
 			if(sqDiff(values[i], c) < sqDiff(values[best], c)) best = i;
 		return values[best];
 	};
@@ -73,7 +73,8 @@ bool kMeans(const Vec3i& contrast, const std::vector<Vec3i>& values, Vec3i& c1, 
 	while(oldC1 != c1 && oldC2 != c2) { // :55-81: stops as soon as EITHER centre is unchanged
 		Vec3i sum1, sum2;
 		int n1 = 0, n2 = 0;
-		for(const Vec3i& v : values) {
+		for(size_t k = 0; k < n; k++) {
+			const Vec3i& v = values[k];
 			if(sqDiff(v, c1) < sqDiff(v, c2)) {
 				sum1 = {sum1.x + v.x, sum1.y + v.y, sum1.z + v.z};
 				n1++;
