@@ -13,6 +13,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 shutil.copy(os.path.join(P, "stats", "s_kernel_stats.csv"), os.path.join(OUT, f"{tag}_kernel_stats.csv"))
 bench = json.loads(open(os.path.join(P, "bench_default.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(OUT, f"{tag}_bench_n1.json"), "w"), indent=1)
+# the bench line printed by the very process rocprofv3 traced: its hipEvent figure for the SAT pass is the one that must agree with
+# the kernel_stats average (the pass moves by +-7 % from process to process on one box, so two separate runs need not agree)
+for line in reversed(open(os.path.join(P, "stats.log")).read().splitlines()):
+    if line.startswith("{") and '"roofline"' in line:
+        traced = json.loads(line)
+        json.dump(traced, open(os.path.join(OUT, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+        break
 
 
 def pmc(name):
