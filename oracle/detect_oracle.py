@@ -577,3 +577,52 @@ def detection_tracking(r: Res, frame):
         for b in frame[key]:
             objs.append(follow(b["x"], b["y"], b["height"], b["orientation"], b["confidence"], int(b["robot_id"]) + off, False))
     r.tracked[frame["camera_id"]] = objs
+
+
+# ---- Perspective::geometryCheck (Perspective.cpp:35-125) ---------------------------------------------------------------
+def geometry_check(cam: Camera, field_length, field_width, boundary_width, boundary_goal_line, ball_radius, geometry_tolerance, max_bot_height, resampling_factor):
+    """Kernel scalars from a camera model (already at the image size): fieldScale, visibleFieldExtent, reprojectedFieldSize,
+    min/max blob radius and the three launch radii (Resources.cpp:160,163; main.cpp:289).  Pure-Python loops: small images only."""
+    w, h = cam.size
+    hgt = F(max_bot_height)
+    goal_b = F(boundary_goal_line if boundary_goal_line >= 0 else boundary_width)
+    lim_x = F(field_length) / F(2) + goal_b
+    lim_y = F(field_width) / F(2) + F(boundary_width)
+    total, n = F(0), 0
+    for y in range(h - 1):
+        for x in range(w - 1):
+            p = cam.image2field((F(x), F(y)), hgt)
+            if fabsf(p[0]) < lim_x and fabsf(p[1]) < lim_y:
+                q = cam.image2field((F(x + 1), F(y)), hgt)
+                s = cam.image2field((F(x), F(y + 1)), hgt)
+                dx = sqrtf((q[0] - p[0]) * (q[0] - p[0]) + (q[1] - p[1]) * (q[1] - p[1]))
+                dy = sqrtf((s[0] - p[0]) * (s[0] - p[0]) + (s[1] - p[1]) * (s[1] - p[1]))
+                total = total + (dx + dy)
+                n += 2
+    with np.errstate(all="ignore"):
+        field_scale = total / F(n) * F(resampling_factor)
+    c = cam.image2field((F(0), F(0)), hgt)
+    ext = [c[0], c[0], c[1], c[1]]
+
+    def upd(p):  # NaN never updates (all comparisons false)
+        if p[0] < ext[0]: ext[0] = p[0]
+        if p[0] > ext[1]: ext[1] = p[0]
+        if p[1] < ext[2]: ext[2] = p[1]
+        if p[1] > ext[3]: ext[3] = p[1]
+
+    for x in range(w):
+        upd(cam.image2field((F(x), F(0)), hgt))
+        upd(cam.image2field((F(x), F(h) - F(1)), hgt))
+    for y in range(h):
+        upd(cam.image2field((F(0), F(y)), hgt))
+        upd(cam.image2field((F(w) - F(1), F(y)), hgt))
+    half_len = F(field_length) / F(2) + goal_b + F(geometry_tolerance)
+    half_wid = F(field_width) / F(2) + F(boundary_width) + F(geometry_tolerance)
+    ext[0], ext[1] = max(ext[0], -half_len), min(ext[1], half_len)
+    ext[2], ext[3] = max(ext[2], -half_wid), min(ext[3], half_wid)
+    size = [int(np.rint((ext[1] - ext[0]) / field_scale)), int(np.rint((ext[3] - ext[2]) / field_scale))]
+    size = [s + 1 if _cmod(s, 2) else s for s in size]
+    min_r = min(F(25.0), F(20.0), F(ball_radius))  # pattern.h:55-56 and the ball
+    max_r = max(F(25.0), F(20.0), F(ball_radius))
+    return {"field_scale": field_scale, "extent": ext, "fw": size[0], "fh": size[1], "min_blob_radius": min_r, "max_blob_radius": max_r,
+            "grad_offset": _idiv(int(math.ceil(max_r / field_scale)), 3), "circle_radius": int(math.ceil(min_r / field_scale)), "list_radius": int(math.floor(min_r / field_scale))}
