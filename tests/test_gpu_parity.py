@@ -220,9 +220,23 @@ RESAMPLE_BATCH_CASES = [
 ]
 
 
+@pytest.fixture(params=["auto", "xcd_bands", "plain"])
+def rs_tile_mapping(request):
+    """The staged resampling kernels pick XCD-contiguous tile bands for large frames only; force both mappings on the small test
+    frames as well (the tile count per frame group is then not a multiple of 8: the remap must stay a bijection)."""
+    old = os.environ.get("VP_RS_XCD")
+    if request.param != "auto":
+        os.environ["VP_RS_XCD"] = "1" if request.param == "xcd_bands" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("VP_RS_XCD", None)
+    else:
+        os.environ["VP_RS_XCD"] = old
+
+
 @pytest.mark.parametrize("cfg,B", RESAMPLE_BATCH_CASES, ids=[c.name for c, _ in RESAMPLE_BATCH_CASES])
 @pytest.mark.parametrize("mode", [0, 1], ids=["nearest", "bilinear_rtz"])
-def test_resample_mapped_batches(gpu, port, cfg, B, mode):
+def test_resample_mapped_batches(gpu, port, cfg, B, mode, rs_tile_mapping):
     """Coordinate-map resampling over whole batches (the staged LDS kernel for Bayer + BILINEAR_RTZ) against the CPU oracle, per frame."""
     capi, ctx, torch = gpu
     model = cfg.model()
