@@ -1,5 +1,6 @@
 // Online colour calibration from the frame's surviving hypotheses (blobs/colorupdate.cpp:21-141).  See detection.h for the
-// parity statement.
+// parity statement.  Written around two small helpers -- an integer colour accumulator and a pull towards (reference, history) --
+// instead of the reference's six parallel variable sets; the arithmetic per channel is the reference's, in its order.
 #include <algorithm>
 #include <cmath>
 
@@ -9,98 +10,98 @@ namespace vp {
 
 namespace {
 
-float sqPointLineSegmentDistance(const FieldLine& line, const Vec2f& point) { // colorupdate.cpp:21-30
-	const Vec2f v{line.p2.x - line.p1.x, line.p2.y - line.p1.y};
-	const Vec2f w{point.x - line.p1.x, point.y - line.p1.y};
-	const float t = std::max(0.0f, std::min(1.0f, (w.x * v.x + w.y * v.y) / (v.x * v.x + v.y * v.y)));
-	const Vec2f delta{w.x - t * v.x, w.y - t * v.y};
-	return delta.x * delta.x + delta.y * delta.y;
+struct ColorSum { // Vector3i sum + count; mean() is the component-wise integer division the reference writes as `sum / n`
+	int r = 0, g = 0, b = 0, n = 0;
+	void add(const Vec3i& c) {
+		r += c.x;
+		g += c.y;
+		b += c.z;
+		n++;
+	}
+	Vec3i mean() const { return {r / n, g / n, b / n}; }
+};
+
+// colorupdate.cpp:73-76: new = referenceForce * reference + historyForce * previous + (1 - referenceForce - historyForce) * measured,
+// per channel in binary32, left to right, truncated towards zero
+struct Pull {
+	float toReference, toHistory, toMeasurement;
+	explicit Pull(const BlobResources& r): toReference(r.referenceForce), toHistory(r.historyForce), toMeasurement(1.0f - r.referenceForce - r.historyForce) {}
+	int channel(int reference, int previous, int measured) const { return (int)(toReference * (float)reference + toHistory * (float)previous + toMeasurement * (float)measured); }
+	Vec3i operator()(const Vec3i& reference, const Vec3i& previous, const Vec3i& measured) const {
+		return {channel(reference.x, previous.x, measured.x), channel(reference.y, previous.y, measured.y), channel(reference.z, previous.z, measured.z)};
+	}
+};
+
+// squared distance of a point to a line segment, projection parameter clamped to the segment (colorupdate.cpp:21-30)
+float segmentDistanceSq(const FieldLine& segment, const Vec2f& q) {
+	const float ax = segment.p2.x - segment.p1.x, ay = segment.p2.y - segment.p1.y;
+	const float bx = q.x - segment.p1.x, by = q.y - segment.p1.y;
+	const float along = std::max(0.0f, std::min(1.0f, (bx * ax + by * ay) / (ax * ax + ay * ay)));
+	const float ex = bx - along * ax, ey = by - along * ay;
+	return ex * ex + ey * ey;
 }
 
-bool ballAtLine(const BlobResources& r, const BallHypothesis& ball) { // :32-55
-	const Perspective& p = *r.perspective;
-	const Vec2f imgPos = p.model.field2image({ball.pos.x, ball.pos.y, (float)r.maxBotHeight});
-	const Vec3f ballPos3 = p.model.image2field(imgPos, p.field.ball_radius);
-	const Vec2f ballPos{ballPos3.x, ballPos3.y};
+// Is the ball candidate, re-projected to ball height, on a painted line or arc (within half the line thickness plus the geometry
+// tolerance)?  colorupdate.cpp:32-55
+bool onFieldMarking(const BlobResources& r, const BallHypothesis& candidate) {
+	const Perspective& view = *r.perspective;
+	const Vec2f pixel = view.model.field2image({candidate.pos.x, candidate.pos.y, (float)r.maxBotHeight});
+	const Vec3f onGround = view.model.image2field(pixel, view.field.ball_radius);
+	const Vec2f q{onGround.x, onGround.y};
+	const float reach = (float)view.field.line_thickness / 2 + r.geometryTolerance;
 
-	const float maxLineDistance = (float)p.field.line_thickness / 2 + r.geometryTolerance;
-	const float sqMaxLineDistance = maxLineDistance * maxLineDistance;
-	for(const FieldLine& line : p.field.field_lines)
-		if(sqPointLineSegmentDistance(line, ballPos) <= sqMaxLineDistance) return true;
+	const float reachSq = reach * reach;
+	for(const FieldLine& segment : view.field.field_lines)
+		if(segmentDistanceSq(segment, q) <= reachSq) return true;
 
-	for(const FieldArc& arc : p.field.field_arcs) {
-		const Vec2f pixel2center{ballPos.x - arc.center.x, ballPos.y - arc.center.y};
-		float angle = atan2f(pixel2center.y, pixel2center.x);
-		if(angle < 0) angle = (float)(angle + 2 * M_PI); // float += double: the sum is formed in double, then narrowed
-		if(fabsf(sqrtf(pixel2center.x * pixel2center.x + pixel2center.y * pixel2center.y) - arc.radius) <= maxLineDistance && angle >= arc.a1 && angle <= arc.a2) return true;
+	for(const FieldArc& arc : view.field.field_arcs) {
+		const float dx = q.x - arc.center.x, dy = q.y - arc.center.y;
+		float bearing = atan2f(dy, dx);
+		if(bearing < 0) bearing = (float)(bearing + 2 * M_PI); // float += double: summed in double, then narrowed
+		const float radial = sqrtf(dx * dx + dy * dy) - arc.radius;
+		if(fabsf(radial) <= reach && bearing >= arc.a1 && bearing <= arc.a2) return true;
 	}
 	return false;
-}
-
-void determineFieldLineBlobColor(BlobResources& r, const std::vector<BallHypothesis>& balls) { // :57-71
-	Vec3i colorSum;
-	int amount = 0;
-	for(const BallHypothesis& ball : balls) {
-		if(ballAtLine(r, ball)) {
-			colorSum = {colorSum.x + ball.blob->color.x, colorSum.y + ball.blob->color.y, colorSum.z + ball.blob->color.z};
-			amount++;
-		}
-	}
-	if(amount > 2) r.fieldLineColor = {colorSum.x / amount, colorSum.y / amount, colorSum.z / amount};
-}
-
-void updateColor(const BlobResources& r, const Vec3i& reference, const Vec3i& oldColor, Vec3i& color) { // :73-76
-	const float updateForce = 1.0f - r.referenceForce - r.historyForce;
-	auto mix = [&](int ref, int old, int cur) { return (int)(r.referenceForce * (float)ref + r.historyForce * (float)old + updateForce * (float)cur); };
-	color = {mix(reference.x, oldColor.x, color.x), mix(reference.y, oldColor.y, color.y), mix(reference.z, oldColor.z, color.z)};
 }
 
 } // namespace
 
 void updateColors(BlobResources& r, const std::vector<BotHypothesis>& bestBotModels, const std::vector<BallHypothesis>& ballCandidates) { // :78-141
-	const Vec3i oldField = r.field, oldOrange = r.orange, oldYellow = r.yellow, oldBlue = r.blue, oldGreen = r.green, oldPink = r.pink;
+	const struct { Vec3i orange, field, yellow, blue, green, pink; } before = {r.orange, r.field, r.yellow, r.blue, r.green, r.pink}; // previous frame's colours: the "history"
+	const Pull pull(r);
 
-	std::vector<Vec3i> centerBlobs;
-	Vec3i pink, green;
-	int pinkN = 0, greenN = 0;
-	for(const BotHypothesis& model : bestBotModels) {
-		if(model.blobs[0] != nullptr) centerBlobs.push_back(model.blobs[0]->color);
-		const int botId = model.botId % 16;
-		for(int i = 1; i < 5; i++) {
-			const Match* blob = model.blobs[i];
-			if(blob == nullptr) continue;
-			if((patterns[botId] >> (4 - i)) & 1) {
-				green = {green.x + blob->color.x, green.y + blob->color.y, green.z + blob->color.z};
-				greenN++;
-			} else {
-				pink = {pink.x + blob->color.x, pink.y + blob->color.y, pink.z + blob->color.z};
-				pinkN++;
-			}
-		}
+	// side blobs vote for green / pink according to the id their robot was given; centre blobs are collected for the team split
+	ColorSum sides[2]; // [0] pink, [1] green
+	std::vector<Vec3i> centres;
+	for(const BotHypothesis& bot : bestBotModels) {
+		if(bot.blobs[0]) centres.push_back(bot.blobs[0]->color);
+		const int code = patterns[bot.botId % 16];
+		for(int slot = 1; slot < 5; slot++)
+			if(bot.blobs[slot]) sides[(code >> (4 - slot)) & 1].add(bot.blobs[slot]->color);
+	}
+	if(sides[0].n > 0) r.pink = pull(r.pinkReference, before.pink, sides[0].mean());
+	if(sides[1].n > 0) r.green = pull(r.greenReference, before.green, sides[1].mean());
+
+	// yellow / blue: two-means over the centre blobs, seeded with the current team colours, contrasted against pink (:123-126)
+	if(kMeans(r.pink, centres, r.yellow, r.blue)) {
+		r.yellow = pull(r.yellowReference, before.yellow, r.yellow);
+		r.blue = pull(r.blueReference, before.blue, r.blue);
 	}
 
-	if(pinkN > 0) {
-		r.pink = {pink.x / pinkN, pink.y / pinkN, pink.z / pinkN};
-		updateColor(r, r.pinkReference, oldPink, r.pink);
-	}
-	if(greenN > 0) {
-		r.green = {green.x / greenN, green.y / greenN, green.z / greenN};
-		updateColor(r, r.greenReference, oldGreen, r.green);
-	}
-
-	if(kMeans(r.pink, centerBlobs, r.yellow, r.blue)) {
-		updateColor(r, r.yellowReference, oldYellow, r.yellow);
-		updateColor(r, r.blueReference, oldBlue, r.blue);
+	// orange / field: two-means over the CENTRE-PIXEL colours of the ball candidates (not their disc means, :131-132), contrasted against blue
+	std::vector<Vec3i> cores;
+	cores.reserve(ballCandidates.size());
+	for(const BallHypothesis& candidate : ballCandidates) cores.push_back(candidate.blob->center);
+	if(kMeans(r.blue, cores, r.orange, r.field)) {
+		r.orange = pull(r.orangeReference, before.orange, r.orange);
+		r.field = pull(r.fieldReference, before.field, r.field);
 	}
 
-	std::vector<Vec3i> ballBlobs; // NB the ball colour model is fed the CENTRE pixel colours, not the disc means (:131-132)
-	for(const BallHypothesis& ball : ballCandidates) ballBlobs.push_back(ball.blob->center);
-	if(kMeans(r.blue, ballBlobs, r.orange, r.field)) {
-		updateColor(r, r.orangeReference, oldOrange, r.orange);
-		updateColor(r, r.fieldReference, oldField, r.field);
-	}
-
-	determineFieldLineBlobColor(r, ballCandidates);
+	// field-line colour: mean disc colour of the candidates that sit on a marking, once there are more than two (:57-71)
+	ColorSum onLines;
+	for(const BallHypothesis& candidate : ballCandidates)
+		if(onFieldMarking(r, candidate)) onLines.add(candidate.blob->color);
+	if(onLines.n > 2) r.fieldLineColor = onLines.mean();
 }
 
 } // namespace vp

@@ -29,24 +29,24 @@ UDPSocket::UDPSocket(const std::string& ip, uint16_t port): impl(new Impl()) {
 	in->sin_family = AF_INET;
 	in->sin_port = htons(port);
 	if(!inet_aton(ip.c_str(), &in->sin_addr)) {
-		fprintf(stderr, "[WARN] Invalid UDP target address %s\n", ip.c_str());
+		fprintf(stderr, "[WARN] vision socket: '%s' is not an IPv4 address\n", ip.c_str());
 		return;
 	}
 	socket_ = socket(AF_INET, SOCK_DGRAM, 0);
 	if(socket_ < 0) {
-		fprintf(stderr, "[WARN] Failed to open UDP socket\n");
+		fprintf(stderr, "[WARN] vision socket: socket() failed\n");
 		return;
 	}
 	const int yes = 1, ttl = 32;
-	if(setsockopt(socket_, SOL_SOCKET, SO_REUSEADDR, &yes, sizeof(yes)) < 0) fprintf(stderr, "[WARN] Setting SO_REUSEADDR on UDP socket failed\n");
-	if(setsockopt(socket_, SOL_SOCKET, SO_BROADCAST, &yes, sizeof(yes)) < 0) fprintf(stderr, "[WARN] Setting SO_BROADCAST on UDP socket failed\n");
-	if(setsockopt(socket_, IPPROTO_IP, IP_MULTICAST_TTL, &ttl, sizeof(ttl)) < 0) fprintf(stderr, "[WARN] Setting TTL failed\n");
-	if(bind(socket_, reinterpret_cast<const sockaddr*>(in), sizeof(*in))) fprintf(stderr, "[WARN] Could not bind to UDP socket %s:%u\n", ip.c_str(), port);
+	if(setsockopt(socket_, SOL_SOCKET, SO_REUSEADDR, &yes, sizeof(yes)) < 0) fprintf(stderr, "[WARN] vision socket: SO_REUSEADDR refused\n");
+	if(setsockopt(socket_, SOL_SOCKET, SO_BROADCAST, &yes, sizeof(yes)) < 0) fprintf(stderr, "[WARN] vision socket: SO_BROADCAST refused\n");
+	if(setsockopt(socket_, IPPROTO_IP, IP_MULTICAST_TTL, &ttl, sizeof(ttl)) < 0) fprintf(stderr, "[WARN] vision socket: multicast TTL refused\n");
+	if(bind(socket_, reinterpret_cast<const sockaddr*>(in), sizeof(*in))) fprintf(stderr, "[WARN] vision socket: bind(%s:%u) failed (another receiver owns the port?)\n", ip.c_str(), port);
 	if(IN_MULTICAST(ntohl(in->sin_addr.s_addr))) {
 		ip_mreq mreq = {};
 		mreq.imr_multiaddr = in->sin_addr;
 		mreq.imr_interface.s_addr = htonl(INADDR_ANY);
-		if(setsockopt(socket_, IPPROTO_IP, IP_ADD_MEMBERSHIP, &mreq, sizeof(mreq)) < 0) fprintf(stderr, "[WARN] Could not join multicast group %s\n", ip.c_str());
+		if(setsockopt(socket_, IPPROTO_IP, IP_ADD_MEMBERSHIP, &mreq, sizeof(mreq)) < 0) fprintf(stderr, "[WARN] vision socket: joining group %s failed\n", ip.c_str());
 	}
 }
 
@@ -75,7 +75,7 @@ UDPSocket::~UDPSocket() {
 bool UDPSocket::send(const uint8_t* data, size_t size) {
 	if(socket_ < 0) return false;
 	if(sendto(socket_, data, size, 0, reinterpret_cast<const sockaddr*>(addr_), sizeof(sockaddr_in)) < 0) {
-		fprintf(stderr, "[WARN] UDP Frame send failed: %s\n", strerror(errno));
+		fprintf(stderr, "[WARN] vision socket: sendto failed: %s\n", strerror(errno));
 		return false;
 	}
 	return true;
@@ -87,7 +87,7 @@ void UDPSocket::run() {
 		const ssize_t bytesRead = read(socket_, msgbuf.data(), msgbuf.size());
 		if(impl->closing) return;
 		if(bytesRead < 0) {
-			fprintf(stderr, "[WARN] UDP Frame recv failed: %s\n", strerror(errno));
+			fprintf(stderr, "[WARN] vision socket: read failed: %s\n", strerror(errno));
 			return;
 		}
 		parse(msgbuf.data(), (int)bytesRead);
