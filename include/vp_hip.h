@@ -265,6 +265,8 @@ int vp_frame(VpContext* ctx, int stream, const VpFrameParams* params, const uint
 int vp_synth_frame(const VpCameraModel* model, int layout, int qw, int qh, float plane_height, float field_len, float field_wid,
 		uint32_t seed, int n_robots, int n_balls, float noise_sigma, uint8_t* raw);
 void vp_synth_camera(int qw, int qh, float cam_height, float plane_height, float visible_len, float distortion, VpCameraModel* out);
+/* ground truth of vp_synth_frame(seed, ...): n x {x, y, radius, r, g, b} discs in field mm (5 per robot, then the balls); returns n */
+int vp_synth_truth(uint32_t seed, int n_robots, int n_balls, float field_len, float field_wid, float* out, int cap);
 
 #ifdef __cplusplus
 }

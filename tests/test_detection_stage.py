@@ -331,3 +331,35 @@ def test_rendered_frames_through_the_hot_path_oracle_yield_the_scene(port):
         assert sorted(int(b["robot_id"]) for b in got["robots_yellow"]) == [i for i in range(cfg.n_robots) if i % 2 == 0]
         assert sorted(int(b["robot_id"]) for b in got["robots_blue"]) == [i for i in range(cfg.n_robots) if i % 2 == 1]
         assert len(got["balls"]) == cfg.n_balls
+
+
+def test_blob_centres_hit_the_rendered_discs(port):
+    """Position accuracy of the hot path's blob list against the synthetic ground truth (the measure of the reference's
+    blob_benchmark, src/blob_benchmark.cpp:44-84), here on the CPU oracle's lists: every rendered disc carries a blob inside it.
+    The peaks sit half a flat pixel up-left of the true centres -- a property of the reference's quadrant bounds (taps at +1 / +r
+    and -1 / -r of an inclusive table, satBlobCenter.cl:37-40: the positive boxes start two pixels out, the negative ones one),
+    reproduced bit for bit by this build; around that offset the sub-pixel estimate scatters by a fraction of a pixel."""
+    import importlib.util, os
+    import oracle as HO
+    spec = importlib.util.spec_from_file_location("blob_accuracy", os.path.join(cases.ROOT, "tools", "blob_accuracy.py"))
+    acc = importlib.util.module_from_spec(spec)
+    old_argv, sys_mod = list(__import__("sys").argv), __import__("sys")
+    sys_mod.argv = ["blob_accuracy.py"]
+    try:
+        spec.loader.exec_module(acc)
+    finally:
+        sys_mod.argv = old_argv
+    cfg = cases.cfgs.T_MID
+    model = HO.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    seeds = [90, 91, 92, 93]
+    lists = []
+    for s in seeds:
+        m, _, _ = port.frame(cfg.synth(s), cfg.layout, cfg.qw, cfg.qh, model, 180.0, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius,
+                             cfg.list_radius, 15.0, 0.0, 2000)
+        lists.append(m)
+    st = acc.accuracy(cfg, lists, seeds)
+    assert st["found"] == st["discs"] == len(seeds) * (5 * cfg.n_robots + cfg.n_balls)
+    assert abs(st["mean_offset_px"][0] + 0.5) < 0.1 and abs(st["mean_offset_px"][1] + 0.5) < 0.1, st["mean_offset_px"]
+    assert st["residual_rms_px"] < 0.35 and st["residual_max_px"] < 1.0, st
+    for kind in ("centre", "side", "ball"):
+        assert st[kind]["max_mm"] < 1.5 * cfg.field_scale, (kind, st[kind])

@@ -74,6 +74,10 @@ class FrameConfig:
         return hostlib.synth_frame(self.model(), self.layout, self.qw, self.qh, self.max_robot_height, self.field_len, self.field_wid,
                                    0x5EED0000 + seed, self.n_robots, self.n_balls, self.noise_sigma)
 
+    def truth(self, seed: int) -> np.ndarray:
+        """Ground truth of synth(seed): (n, 6) {x, y, radius, r, g, b} discs in field mm on the plane z = max_robot_height."""
+        return hostlib.synth_truth(0x5EED0000 + seed, self.n_robots, self.n_balls, self.field_len, self.field_wid)
+
     def with_(self, **kw) -> "FrameConfig":
         return replace(self, **kw)
 

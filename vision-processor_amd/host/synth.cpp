@@ -196,6 +196,25 @@ extern "C" int vp_synth_frame(const VpCameraModel* model, int layout, int qw, in
 	return VP_OK;
 }
 
+// Ground truth of a synthetic frame: the discs buildScene() places for this seed, in field coordinates on the plane the scene is
+// rendered on.  out = n x {x, y, radius, r, g, b}; returns the number of discs (5 per robot, then the balls), at most cap are written.
+extern "C" int vp_synth_truth(uint32_t seed, int nRobots, int nBalls, float fieldLen, float fieldWid, float* out, int cap) {
+	if(nRobots < 0 || nBalls < 0 || (cap > 0 && !out)) return VP_ERR_INVALID;
+	Scene scene;
+	buildScene(scene, seed, nRobots, nBalls, fieldLen, fieldWid);
+	const int n = (int)scene.discs.size();
+	for(int i = 0; i < std::min(n, cap); i++) {
+		const Disc& d = scene.discs[i];
+		out[6 * i] = (float)d.x;
+		out[6 * i + 1] = (float)d.y;
+		out[6 * i + 2] = (float)d.r;
+		out[6 * i + 3] = d.rgb[0];
+		out[6 * i + 4] = d.rgb[1];
+		out[6 * i + 5] = d.rgb[2];
+	}
+	return n;
+}
+
 // Nadir camera over the field centre: q = (w 0, x -1, y 0, z 0) (CameraModel.h:50) => R = diag(1, -1, -1);
 // focal length such that `visibleLen` mm of the plane z = planeHeight spans the quad-plane width (distortion ignored).
 extern "C" void vp_synth_camera(int qw, int qh, float camHeight, float planeHeight, float visibleLen, float distortion, VpCameraModel* out) {

@@ -31,6 +31,7 @@ def lib():
         _lib.vp_synth_frame.restype = C.c_int
         _lib.vp_synth_camera.restype = None
         _lib.vp_geometry_check.restype = C.c_int
+        _lib.vp_synth_truth.restype = C.c_int
     return _lib
 
 
@@ -48,6 +49,15 @@ def synth_frame(model, layout, qw, qh, plane_height, field_len, field_wid, seed,
     if rc != 0:
         raise RuntimeError(f"vp_synth_frame failed: {rc}")
     return raw
+
+
+def synth_truth(seed, n_robots, n_balls, field_len, field_wid) -> np.ndarray:
+    """Ground-truth discs of synth_frame(seed, ...): (n, 6) float32 rows {x, y, radius, r, g, b} in field mm."""
+    n = 5 * int(n_robots) + int(n_balls)
+    out = np.zeros((max(n, 1), 6), np.float32)
+    got = lib().vp_synth_truth(C.c_uint32(seed & 0xFFFFFFFF), int(n_robots), int(n_balls), C.c_float(field_len), C.c_float(field_wid), out.ctypes.data_as(C.c_void_p), n)
+    assert got == n, (got, n)
+    return out[:n]
 
 
 def geometry_check(calib, img_w, img_h, calib_w, calib_h, field, ball_radius=21.5, geometry_tolerance=10.0, max_bot_height=180.0, resampling_factor=1.0):
