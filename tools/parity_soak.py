@@ -1,0 +1,53 @@
+"""Randomised differential soak of the whole hot path against the CPU oracle (tools only; GPU).  For each seed a synthetic frame of
+a small configuration (every layout, both sampler modes, ragged sizes, varying batch sizes and both list orders) is pushed through
+vp_frame and through oracle/vp_oracle.c; flat, SAT, counters and the sorted blob records must be byte-identical.
+usage: parity_soak.py [SECONDS]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import numpy as np, torch
+from _vp_pkg import load
+import oracle as O
+vp = load(); capi = vp.load_capi(); cfgs = vp.configs
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+O.build(ref=False)
+port = O.Port(threads=8)
+ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+rng = np.random.default_rng(2024)
+pool = [cfgs.T_MID, cfgs.T_RGGB, cfgs.T_GRBG, cfgs.T_BGR, cfgs.T_RAGGED, cfgs.T_RAGGED.with_(name="t_ragged_even", qw=68, qh=46), cfgs.CFG1]
+t0, frames, launches, seed = time.time(), 0, 0, 10_000
+while time.time() - t0 < budget:
+    cfg = pool[int(rng.integers(len(pool)))]
+    mode = int(rng.integers(2))
+    B = int(rng.choice([1, 1, 2, 3, 5, 17]))
+    order = capi.ORDER_RASTER if rng.integers(2) else capi.ORDER_ATOMIC
+    variant = capi.SAT_TILED if rng.integers(4) else capi.SAT_TWOPASS
+    mm = cfg.max_matches
+    raws = [cfg.synth(seed + i) for i in range(B)]
+    seed += B
+    p = capi.frame_params(cfg, sat_variant=variant, order=order, sampler_mode=mode, use_coord_map=bool(rng.integers(2)))
+    d_raw = torch.from_numpy(np.stack(raws)).cuda()
+    flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+    sat = torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
+    matches = torch.zeros((B, 22 * mm), dtype=torch.uint8, device="cuda")
+    idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+    counter = torch.zeros((B, 3), dtype=torch.int32, device="cuda")
+    ctx.frame(p, d_raw, B, flat, sat, matches, counter, idx=idx)
+    ctx.sync()
+    launches += 1
+    hf, hs, hm, hi, hc = flat.cpu().numpy(), sat.cpu().numpy(), matches.cpu().numpy(), idx.cpu().numpy().view(np.uint32), counter.cpu().numpy()
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    for i in range(B):
+        planes = port.raw2quad(raws[i], cfg.layout, cfg.qw, cfg.qh)
+        wflat = port.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, mode, cfg.fw, cfg.fh)
+        wsat = port.sat_i32(port.graddot(wflat, cfg.grad_offset))[0]
+        m, wi, wc = port.frame(raws[i], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, mode, cfg.fw, cfg.fh,
+                               cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+        tag = f"{cfg.name} mode {mode} batch {B} frame {i} seed {seed - B + i} order {order} sat {variant}"
+        assert np.array_equal(hf[i], wflat), "flat: " + tag
+        assert np.array_equal(hs[i], wsat), "SAT: " + tag
+        assert np.array_equal(hc[i], wc), "counter: " + tag
+        gm, gi = capi.sorted_blobs(hm[i], hi[i], hc[i], mm)
+        assert np.array_equal(gi, wi) and gm.tobytes() == m.tobytes(), "blob records: " + tag
+        frames += 1
+print(f"parity soak: {frames} frames in {launches} launches over {len(pool)} configurations, {time.time() - t0:.0f} s: flat, SAT, counters and blob records byte-identical to the CPU oracle")
