@@ -207,8 +207,9 @@ def main():
         for i in range(B):
             dcfg.cam_id = rank * B + i  # every feed slot is its own camera: own colour model, own tracker
             d = hostlib.Detector(dcfg)
+            lines, arcs = cfg.field_markings()
             d.set_geometry_direct(hostlib.nadir_calib(cfg.model()), (cfg.qw, cfg.qh), cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh,
-                                  field=(int(cfg.field_len), int(cfg.field_wid), 300, -1, 10))
+                                  field=(int(cfg.field_len), int(cfg.field_wid), 300, -1, 10), lines=lines, arcs=arcs)
             det["detectors"].append(d)
 
     def cpu_stage(p, frame_no):

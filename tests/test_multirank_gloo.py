@@ -99,7 +99,9 @@ def _packets(rank, batch, cfg, mm, steps, threads):
     for i in range(batch):
         dcfg.cam_id = rank * batch + i
         d = H.Detector(dcfg)
-        d.set_geometry_direct(H.nadir_calib(cfg.model()), (cfg.qw, cfg.qh), cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, field=(int(cfg.field_len), int(cfg.field_wid), 300, -1, 10))
+        lines, arcs = cfg.field_markings()
+        d.set_geometry_direct(H.nadir_calib(cfg.model()), (cfg.qw, cfg.qh), cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, field=(int(cfg.field_len), int(cfg.field_wid), 300, -1, 10),
+                              lines=lines, arcs=arcs)
         dets.append(d)
     counter, matches, _ = _detections(rank, batch, cfg, mm)
     packets = np.zeros((batch, f.PACKET_CAP), np.uint8)

@@ -78,6 +78,14 @@ class FrameConfig:
         """Ground truth of synth(seed): (n, 6) {x, y, radius, r, g, b} discs in field mm on the plane z = max_robot_height."""
         return hostlib.synth_truth(0x5EED0000 + seed, self.n_robots, self.n_balls, self.field_len, self.field_wid)
 
+    def field_markings(self):
+        """The painted markings of the synthetic scene (host/synth.cpp shade(): touch lines, goal lines, halfway line, centre
+        circle) as SSL_FieldLineSegment / SSL_FieldCircularArc data: (lines n x {p1x, p1y, p2x, p2y}, arcs n x {cx, cy, radius, a1, a2})."""
+        hl, hw = self.field_len / 2.0, self.field_wid / 2.0
+        lines = [(-hl, -hw, hl, -hw), (-hl, hw, hl, hw), (-hl, -hw, -hl, hw), (hl, -hw, hl, hw), (0.0, -hw, 0.0, hw)]
+        arcs = [(0.0, 0.0, min(self.field_len, self.field_wid) * 0.07, 0.0, 2.0 * np.pi)]
+        return lines, arcs
+
     def with_(self, **kw) -> "FrameConfig":
         return replace(self, **kw)
 
