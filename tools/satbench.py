@@ -31,10 +31,11 @@ def run(variant, N=10):
     return e0.elapsed_time(e1) / N * 1000
 for rnd in range(6):
     for v in variants:
-        os.environ['VP_SAT_DEBUG'] = str(v)
+        if v: os.environ['VP_SAT_DEBUG'] = str(v)
+        else: os.environ.pop('VP_SAT_DEBUG', None)  # 0 = the shipped path (k_sat_fast2): any VP_SAT_DEBUG value selects the instrumented first-generation kernel
         t = run(0, 3) if rnd == 0 else run(0)
         if rnd: res[v].append(t)
-os.environ['VP_SAT_DEBUG'] = '0'
+os.environ.pop('VP_SAT_DEBUG', None)
 if os.environ.get("VP_TWOPASS"):
     for _ in range(3): res['twopass'].append(run(1))
 for v, ts in res.items():
