@@ -86,6 +86,30 @@ def main():
         np.savez_compressed(path, **out)
         total += os.path.getsize(path)
         print(f"{name}: blobs={len(m)} counter={cnt.tolist()} max|SAT|={max_sat:.0f} ({os.path.getsize(path) // 1024} KiB)")
+    # BASELINE config 0 at its own size: one 640x480 BGR frame (the OpenCV-driver layout) through the reference's kernels, both sampler
+    # modes.  Compact form: the input frame, the blob list and counters, and SHA-256 digests of every intermediate image.
+    import hashlib
+    cfg, seed = cases.cfgs.CFG1, 7
+    raw = cfg.synth(seed)
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    out = dict(raw=raw, model=model.to_array(), layout=np.int32(cfg.layout), qw=np.int32(cfg.qw), qh=np.int32(cfg.qh), fw=np.int32(cfg.fw), fh=np.int32(cfg.fh),
+               scalars=np.array([cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.circ_threshold, cfg.min_score], np.float32),
+               ints=np.array([cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.max_matches], np.int32))
+    digest = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    planes = ref.raw2quad(raw, cfg.layout, cfg.qw, cfg.qh)
+    out["sha_planes"] = digest(planes[:3])
+    for mode in (0, 1):
+        flat = ref.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, mode, cfg.fw, cfg.fh)
+        ch = ref.chain_from_flat(flat, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, cfg.max_matches)
+        assert float(np.abs(ch["sat"]).max()) < 2 ** 24
+        out[f"m{mode}_matches"] = np.frombuffer(ch["matches"].tobytes(), np.uint8)
+        out[f"m{mode}_idx"], out[f"m{mode}_counter"] = ch["idx"], ch["counter"]
+        out[f"m{mode}_sha_flat"], out[f"m{mode}_sha_graddot"] = digest(flat), digest(exact_i32(ch["graddot"], "graddot"))
+        out[f"m{mode}_sha_sat"], out[f"m{mode}_sha_blobcenter"] = digest(exact_i32(ch["sat"], "sat")), digest(ch["blobcenter"])
+        print(f"config0 {cfg.name} mode {mode}: blobs={len(ch['matches'])} counter={ch['counter'].tolist()}")
+    path = os.path.join(cases.GOLDEN_DIR, "config0_640x480_bgr.npz")
+    np.savez_compressed(path, **out)
+    total += os.path.getsize(path)
     print(f"total {total // 1024} KiB")
 
 

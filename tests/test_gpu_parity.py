@@ -540,3 +540,32 @@ def test_abi_memory_and_events(gpu):
             ctx.free(p)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["nearest", "bilinear_rtz"])
+def test_config0_640x480_bgr_frame(gpu, mode):
+    """BASELINE config 0 at its own size (one 640x480 BGR frame): the HIP path against the fixture generated from the reference's own
+    compiled kernels -- digests of flat and SAT, counters, pixel indices and blob records."""
+    import hashlib
+    capi, ctx, torch = gpu
+    g = cases.load_golden("config0_640x480_bgr")
+    cfg = cfgs.CFG1
+    assert (int(g["qw"]), int(g["qh"]), int(g["fw"]), int(g["fh"]), int(g["layout"])) == (cfg.qw, cfg.qh, cfg.fw, cfg.fh, cfg.layout)
+    assert np.array_equal(np.frombuffer(bytes(cfg.model()), np.uint8), g["model"].view(np.uint8).reshape(-1))
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    mm = cfg.max_matches
+    for variant, use_map in ((capi.SAT_TILED, True), (capi.SAT_TWOPASS, False)):
+        p = capi.frame_params(cfg, sat_variant=variant, order=capi.ORDER_RASTER, sampler_mode=mode, use_coord_map=use_map)
+        d = dict(flat=torch.zeros((cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+                 matches=torch.zeros(mm * 22, dtype=torch.uint8, device="cuda"), idx=torch.zeros(mm, dtype=torch.int32, device="cuda"),
+                 counter=torch.zeros(3, dtype=torch.int32, device="cuda"))
+        views = dict(planes=torch.zeros((4, cfg.qh, cfg.qw), dtype=torch.uint8, device="cuda"), graddot=torch.zeros((cfg.fh, cfg.fw), dtype=torch.float32, device="cuda"),
+                     blobcenter=torch.zeros((cfg.fh, cfg.fw), dtype=torch.float32, device="cuda"))
+        ctx.frame(p, dev(torch, g["raw"]), 1, **d, **views)
+        ctx.sync()
+        assert np.array_equal(sha(host(views["planes"])[:3]), g["sha_planes"])
+        assert np.array_equal(sha(host(d["flat"])), g[f"m{mode}_sha_flat"])
+        assert np.array_equal(sha(host(views["graddot"]).astype(np.int32)), g[f"m{mode}_sha_graddot"])
+        assert np.array_equal(sha(host(d["sat"])), g[f"m{mode}_sha_sat"])
+        assert np.array_equal(sha(host(views["blobcenter"])), g[f"m{mode}_sha_blobcenter"])
+        assert_list_equal(capi, (host(d["matches"]), host(d["idx"]).view(np.uint32), host(d["counter"])), g[f"m{mode}_matches"], g[f"m{mode}_idx"], g[f"m{mode}_counter"], mm)

@@ -91,3 +91,33 @@ def test_edge_cases_do_what_they_claim():
     g = cases.load_golden("flat_offset0")
     assert not g["graddot"].any() and g["counter"][0] == 0
     assert "sat_f32" in cases.load_golden("flat_guard_violation")
+
+
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["nearest", "bilinear_rtz"])
+def test_config0_640x480_bgr_frame(port, mode):
+    """BASELINE config 0 at its own size: one 640x480 BGR frame (OpenCV-driver layout).  The fixture holds the input, the blob list the
+    reference's own compiled kernels produce and SHA-256 digests of their intermediate images; the port must reproduce all of them."""
+    g = cases.load_golden("config0_640x480_bgr")
+    model = O.CameraModel.from_array(g["model"])
+    mrh, fs, ox, oy, thr, min_score = [float(v) for v in g["scalars"]]
+    o, r, R, mm = [int(v) for v in g["ints"]]
+    qw, qh, fw, fh, layout = int(g["qw"]), int(g["qh"]), int(g["fw"]), int(g["fh"]), int(g["layout"])
+    assert (qw, qh, fw, fh, layout) == (640, 480, 640, 480, 2)
+    planes = port.raw2quad(g["raw"], layout, qw, qh)
+    assert np.array_equal(_sha(planes[:3]), g["sha_planes"])
+    flat = port.resample(planes, layout, model, mrh, fs, ox, oy, mode, fw, fh)
+    assert np.array_equal(_sha(flat), g[f"m{mode}_sha_flat"])
+    gd = port.graddot(flat, o)
+    assert np.array_equal(_sha(gd.astype(np.int32)), g[f"m{mode}_sha_graddot"])
+    sat = port.sat_vertical(port.sat_horizontal(gd))
+    assert np.array_equal(_sha(sat.astype(np.int32)), g[f"m{mode}_sha_sat"])
+    bc = port.blobcenter(sat, r)
+    assert np.array_equal(_sha(bc), g[f"m{mode}_sha_blobcenter"])
+    m, idx, cnt = port.bloblist(flat, bc, thr, min_score, R, mm)
+    assert np.array_equal(cnt, g[f"m{mode}_counter"]) and np.array_equal(idx, g[f"m{mode}_idx"])
+    assert m.tobytes() == g[f"m{mode}_matches"].tobytes() and len(m) > 20
