@@ -1,5 +1,8 @@
-"""A/B timing of the coordinate-map resampling kernel (tools only).  usage: rsbench.py BATCH [VP_RS_FLT values ...]"""
+"""A/B timing of the coordinate-map resampling kernel over the values of one environment switch, interleaved in one process, with a
+bit-for-bit comparison of the outputs (tools only).  usage: rsab.py BATCH VALUE [VALUE ...]   (switch: $VP_AB_VAR, default VP_RS_FLT;
+e.g. VP_AB_VAR=VP_RS_XCD rsab.py 128 0 1)"""
 import os, sys
+VAR = os.environ.get('VP_AB_VAR', 'VP_RS_FLT')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from _vp_pkg import load
@@ -23,20 +26,20 @@ def run(N=10):
     return e0.elapsed_time(e1) / N * 1000
 for rnd in range(6):
     for v in variants:
-        os.environ['VP_RS_FLT'] = str(v)
+        os.environ[VAR] = str(v)
         t = run(3) if rnd == 0 else run()
         if rnd: res[v].append(t)
 for v, ts in res.items():
     med = float(np.median(ts))
-    print(f"resample {cfg.name} B={B} VP_RS_FLT={v}: median {med:.1f} us/launch (min {min(ts):.1f}), {med/B:.2f} us/frame")
+    print(f"resample {cfg.name} B={B} {VAR}={v}: median {med:.1f} us/launch (min {min(ts):.1f}), {med/B:.2f} us/frame")
 # the variants must agree bit for bit
 outs = {}
 for v in variants:
-    os.environ['VP_RS_FLT'] = str(v)
+    os.environ[VAR] = str(v)
     flat.zero_()
     ctx.resample_raw_mapped(raw, cfg.layout, cfg.qw, cfg.qh, d_map, int(os.environ.get("VP_MODE", "1")), cfg.fw, cfg.fh, B, flat)
     torch.cuda.synchronize()
     outs[v] = flat.clone()
 ref = outs[variants[0]]
 for v in variants[1:]:
-    print(f"VP_RS_FLT={v} equals VP_RS_FLT={variants[0]}: {bool(torch.equal(outs[v], ref))}")
+    print(f"{VAR}={v} equals {VAR}={variants[0]}: {bool(torch.equal(outs[v], ref))}")
