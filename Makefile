@@ -2,7 +2,7 @@
 #   make            -> hip + host + oracle (+ oracle/_ref when /root/reference exists)
 #   make hip        -> vision-processor_amd/libvp_hip.so   (hand-written HIP kernels + C ABI, gfx950)
 #   make host       -> vision-processor_amd/libvp_host.so  (C++ host side: synthetic frames, geometry)
-#   make facade     -> vision-processor_amd/host/vp_frame_loop (C++ facade demo of main.cpp:262-317)
+#   make facade     -> vision-processor_amd/host/vp_frame_loop (C++ facade demo of main.cpp:262-372) and host/vp_feeds (many feeds, C ABI only)
 PKG      := vision-processor_amd
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
@@ -28,16 +28,20 @@ $(PKG)/libvp_host.so: $(HOST_SRCS) include/vp_hip.h include/vp_host.h $(wildcard
 	g++ $(CXXFLAGS) -shared -o $@ $(HOST_SRCS)
 
 ifneq ($(wildcard $(PKG)/host/frame_loop.cpp),)
-facade: $(PKG)/host/vp_frame_loop
+facade: $(PKG)/host/vp_frame_loop $(PKG)/host/vp_feeds
 else
 facade:
 endif
 $(PKG)/host/vp_frame_loop: $(FACADE_SRCS) $(wildcard $(PKG)/host/*.h) $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
 	g++ $(CXXFLAGS) -o $@ $(FACADE_SRCS) -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
+# many feeds on one GPU, C++ on the C ABI alone (vp_frame + read-back + vph_detect_batch, CPU stage overlapped with the next step)
+$(PKG)/host/vp_feeds: $(PKG)/host/feeds_main.cpp include/vp_hip.h include/vp_host.h $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
+	g++ $(CXXFLAGS) -o $@ $(PKG)/host/feeds_main.cpp -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
 oracle:
 	$(MAKE) -s -C oracle oracle ref
 
 clean:
-	rm -f $(PKG)/libvp_hip.so $(PKG)/libvp_host.so $(PKG)/host/vp_frame_loop
+	rm -f $(PKG)/libvp_hip.so $(PKG)/libvp_host.so $(PKG)/host/vp_frame_loop $(PKG)/host/vp_feeds
 	$(MAKE) -s -C oracle clean

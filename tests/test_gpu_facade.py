@@ -144,3 +144,18 @@ def test_frame_loop_emits_the_oracles_detection_packets(mode, tmp_path):
         total_bots += len(d.robots_yellow) + len(d.robots_blue)
         assert f"frame {k + 1}: {len(m)} blobs {len(d.balls)} balls {len(d.robots_yellow) + len(d.robots_blue)} bots" in stdout
     assert total_bots >= frames  # the rendered robots are found in every frame
+
+
+def test_native_multi_feed_pipeline():
+    """host/vp_feeds: several camera feeds through vp_frame + read-back + the CPU stage on host threads, C++ on the C ABI alone (no
+    PyTorch in the process: the library runs on the system HIP runtime).  Every rendered robot and ball of every feed is reported."""
+    import json
+    exe = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_feeds")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe, "6", "4", "1", "4", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["feeds"] == 6 and r["steps"] == 4 and r["detect"] == 1
+    assert r["robots_per_frame"] == 16.0 and 8.0 <= r["balls_per_frame"] <= 9.0 and 100 < r["blobs_per_frame"] < 200
+    assert 500 < r["packet_bytes_per_frame"] < 1500 and r["frames_per_s"] > 100

@@ -1,0 +1,182 @@
+// vp_feeds: `feeds` independent camera feeds through the whole chain on one GPU, in C++ on the C ABI alone (no Python, no PyTorch):
+//   vp_frame (one launch group per step) -> read-back of counters + blob records -> per feed: hypotheses, SSL_DetectionFrame,
+//   tracker, SSL_WrapperPacket (vph_detect_batch on host threads), the CPU stage of step k running while the GPU works on step k + 1.
+// This is the loop of src/main.cpp:262-372 for many cameras at once: what a deployment that puts several cameras on one MI355X runs.
+//
+// usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1]
+// Scene and geometry: SURVEY.md 8(d) cfg2 (2048x1536 RGGB, nadir camera 5 m over a 9.6 x 7.2 m patch, 16 robots, 8 balls per feed).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "vp_hip.h"
+#include "vp_host.h"
+
+#define CK(call) \
+	do { \
+		const int rc_ = (call); \
+		if(rc_ != VP_OK) { \
+			fprintf(stderr, "[FATAL] %s failed (%d): %s\n", #call, rc_, vp_last_error()); \
+			exit(1); \
+		} \
+	} while(0)
+
+int main(int argc, char** argv) {
+	const int feeds = argc > 1 ? atoi(argv[1]) : 128, steps = argc > 2 ? atoi(argv[2]) : 20, warmup = argc > 3 ? atoi(argv[3]) : 3;
+	const int threads = argc > 4 ? atoi(argv[4]) : 16, detect = argc > 5 ? atoi(argv[5]) : 1;
+	if(feeds < 1 || steps < 1 || warmup < 0 || threads < 1) {
+		fprintf(stderr, "usage: vp_feeds [feeds] [steps] [warmup] [host_threads] [detect 0|1]\n");
+		return 2;
+	}
+	// cfg2: kernel scalars assigned directly
+	const int qw = 1024, qh = 768, fw = 2048, fh = 1536, maxBlobs = 2000, robots = 16, balls = 8;
+	const float fieldScale = 4.6875f, offX = -4800.f, offY = -3600.f, planeHeight = 180.f, fieldLen = 9000.f, fieldWid = 6000.f;
+	VpFrameParams p;
+	memset(&p, 0, sizeof(p));
+	p.layout = VP_LAYOUT_RGGB;
+	p.qw = qw;
+	p.qh = qh;
+	vp_synth_camera(qw, qh, 5000.f, planeHeight, 9600.f, 0.08f, &p.model);
+	p.max_robot_height = planeHeight;
+	p.field_scale = fieldScale;
+	p.off_x = offX;
+	p.off_y = offY;
+	p.fw = fw;
+	p.fh = fh;
+	p.grad_offset = (int)ceilf(25.0f / fieldScale) / 3; // Resources.cpp:160
+	p.circle_radius = (int)ceilf(20.0f / fieldScale);  // :163
+	p.list_radius = (int)floorf(20.0f / fieldScale);   // main.cpp:289
+	p.circ_threshold = 15.0f;
+	p.min_score = 0.0f;
+	p.max_matches = maxBlobs;
+	p.sampler_mode = VP_SAMPLER_BILINEAR_RTZ;
+	p.sat_variant = VP_SAT_TILED;
+	p.order = VP_ORDER_RASTER;
+	p.use_coord_map = 1;
+
+	VpContext* ctx = nullptr;
+	CK(vp_ctx_create(0, 2, &ctx));
+	const size_t rawBytes = (size_t)4 * qw * qh, npx = (size_t)fw * fh;
+	// synthetic feeds, resident in HBM before the clock starts
+	uint8_t* dRaw = nullptr;
+	CK(vp_malloc_device(ctx, rawBytes * feeds, (void**)&dRaw));
+	{
+		std::vector<uint8_t> frame(rawBytes);
+		for(int i = 0; i < feeds; i++) {
+			CK(vp_synth_frame(&p.model, p.layout, qw, qh, planeHeight, fieldLen, fieldWid, 0x5EED0000u + (uint32_t)i, robots, balls, 3.0f, frame.data()));
+			CK(vp_copy_h2d(ctx, 0, dRaw + rawBytes * i, frame.data(), rawBytes));
+			CK(vp_sync(ctx, 0));
+		}
+	}
+	// two sets of per-step buffers: step k runs on stream k & 1 while the host reads step k - 1 back from the other set
+	VpFrameBuffers buf[2];
+	void* hMatches[2];
+	void* hCounter[2];
+	const size_t matchBytes = sizeof(VpMatch) * (size_t)maxBlobs * feeds, counterBytes = sizeof(int32_t) * 3 * (size_t)feeds;
+	for(int s = 0; s < 2; s++) {
+		memset(&buf[s], 0, sizeof(buf[s]));
+		CK(vp_malloc_device(ctx, npx * 4 * feeds, (void**)&buf[s].flat));
+		CK(vp_malloc_device(ctx, npx * 4 * feeds, (void**)&buf[s].sat));
+		CK(vp_malloc_device(ctx, matchBytes, (void**)&buf[s].matches));
+		CK(vp_malloc_device(ctx, sizeof(uint32_t) * (size_t)maxBlobs * feeds, (void**)&buf[s].idx));
+		CK(vp_malloc_device(ctx, counterBytes, (void**)&buf[s].counter));
+		CK(vp_malloc_host(ctx, matchBytes, &hMatches[s]));
+		CK(vp_malloc_host(ctx, counterBytes, &hCounter[s]));
+	}
+	// one detector per feed: own colour model, own tracker (main.cpp runs one process per camera)
+	std::vector<VphDetector*> detectors;
+	const float calib[11] = {p.model.f, p.model.p[0], p.model.p[1], p.model.d, -1.f, 0.f, 0.f, 0.f, -p.model.c[0], p.model.c[1], p.model.c[2]}; // nadir: t = R (-pos)
+	const int32_t field[5] = {(int32_t)fieldLen, (int32_t)fieldWid, 300, -1, 10};
+	if(detect)
+		for(int i = 0; i < feeds; i++) {
+			VphConfig cfg;
+			vph_config_defaults(&cfg);
+			cfg.cam_id = i;
+			VphDetector* d = vph_detector_create(&cfg);
+			if(!d || vph_detector_set_geometry_direct(d, calib, qw, qh, fieldScale, offX, offY, fw, fh, field, 21.5f, 90.f, nullptr, 0, nullptr, 0) != VP_OK) {
+				fprintf(stderr, "[FATAL] detector %d\n", i);
+				return 1;
+			}
+			detectors.push_back(d);
+		}
+	const int packetCap = 4092;
+	std::vector<uint8_t> packets((size_t)feeds * packetCap);
+	std::vector<int32_t> lengths(feeds);
+
+	long blobs = 0, packetBytes = 0;
+	double waitMs = 0, stageMs = 0, launchMs = 0;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	auto cpuStage = [&](int s, int frameNo) { // the read-back of step `frameNo` sits in host set s
+		const auto w0 = now();
+		CK(vp_sync(ctx, s));
+		const auto w1 = now();
+		waitMs += ms(w0, w1);
+		const int32_t* c = static_cast<const int32_t*>(hCounter[s]);
+		for(int i = 0; i < feeds; i++) blobs += c[3 * i] < maxBlobs ? c[3 * i] : maxBlobs;
+		if(!detect) return;
+		const double t = frameNo / 70.0;
+		CK(vph_detect_batch(detectors.data(), feeds, static_cast<const VpMatch*>(hMatches[s]), c, maxBlobs, (uint32_t)frameNo, t, t, t + 0.002, threads, packets.data(), packetCap,
+				lengths.data()));
+		for(int i = 0; i < feeds; i++) packetBytes += lengths[i] > 0 ? lengths[i] : 0;
+		stageMs += ms(w1, now());
+	};
+	auto launch = [&](int k) {
+		const auto l0 = now();
+		const int s = k & 1;
+		CK(vp_frame(ctx, s, &p, dRaw, feeds, &buf[s]));
+		CK(vp_copy_d2h(ctx, s, hCounter[s], buf[s].counter, counterBytes));
+		CK(vp_copy_d2h(ctx, s, hMatches[s], buf[s].matches, matchBytes));
+		launchMs += ms(l0, now());
+	};
+
+	int k = 0;
+	for(; k < warmup; k++) {
+		launch(k);
+		if(k > 0) cpuStage((k - 1) & 1, k);
+	}
+	if(k > 0) cpuStage((k - 1) & 1, k);
+	CK(vp_sync(ctx, -1));
+	blobs = packetBytes = 0;
+	waitMs = stageMs = launchMs = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	for(int j = 0; j < steps; j++, k++) {
+		launch(k);
+		if(j > 0) cpuStage((k - 1) & 1, k); // steps are numbered from 1: step k's blobs while the GPU works on step k + 1
+	}
+	cpuStage((k - 1) & 1, k);
+	CK(vp_sync(ctx, -1));
+	const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+	int robotsSeen = 0, ballsSeen = 0;
+	if(detect)
+		for(VphDetector* d : detectors) {
+			VphFrameHeader h;
+			vph_frame_header(d, &h);
+			robotsSeen += h.n_robots_yellow + h.n_robots_blue;
+			ballsSeen += h.n_balls;
+		}
+	printf("{\"program\": \"vp_feeds\", \"feeds\": %d, \"steps\": %d, \"host_threads\": %d, \"detect\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"blobs_per_frame\": %.2f", feeds,
+			steps, threads, detect, feeds * (double)steps / dt, 1e3 * dt / steps, blobs / ((double)feeds * steps));
+	if(detect)
+		printf(", \"robots_per_frame\": %.3f, \"balls_per_frame\": %.3f, \"packet_bytes_per_frame\": %.1f, \"rendered\": {\"robots\": %d, \"balls\": %d}", robotsSeen / (double)feeds,
+				ballsSeen / (double)feeds, packetBytes / ((double)feeds * steps), robots, balls);
+	printf(", \"host_ms_per_step\": {\"launch\": %.3f, \"wait_for_gpu\": %.3f, \"cpu_stage\": %.3f}}\n", launchMs / steps, waitMs / steps, stageMs / steps);
+
+	for(VphDetector* d : detectors) vph_detector_destroy(d);
+	for(int s = 0; s < 2; s++) {
+		vp_free_device(ctx, buf[s].flat);
+		vp_free_device(ctx, buf[s].sat);
+		vp_free_device(ctx, buf[s].matches);
+		vp_free_device(ctx, buf[s].idx);
+		vp_free_device(ctx, buf[s].counter);
+		vp_free_host(ctx, hMatches[s]);
+		vp_free_host(ctx, hCounter[s]);
+	}
+	vp_free_device(ctx, dRaw);
+	vp_ctx_destroy(ctx);
+	return 0;
+}
