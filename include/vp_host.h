@@ -101,6 +101,12 @@ int vph_encode(const VphDetector* d, uint8_t* buf, int cap);
 /* VisionSocket::parse (udpsocket.cpp:146-154): 1 = packet carried a detection (now the current frame), 0 = none, <0 malformed */
 int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source);
 
+/* VisionSocket::parse + geometryCheck for a geometry packet (udpsocket.cpp:113-130,156-162; Perspective.cpp:35-125): when the packet
+ * carries SSL_GeometryData with a calibration for this detector's camera id, the geometry is installed and the kernel scalars are
+ * derived for a sensor of img_w x img_h quad pixels.  Returns 1 = applied, 0 = no geometry / no calibration for this camera, < 0 =
+ * malformed.  out_f / out_i / out_model as vp_geometry_check (may be NULL). */
+int vph_apply_geometry_packet(VphDetector* d, const uint8_t* buf, int len, int img_w, int img_h, float resampling_factor, float* out_f, int32_t* out_i, VpCameraModel* out_model);
+
 /* VisionSocket (udpsocket.h:67-113): attach a datagram socket to the detector.  vph_udp_send emits the current frame's packet to
  * (ip, port) (a multicast group such as 224.5.23.2:10006, or a unicast address); a receiver thread parses every datagram that
  * arrives there -- the detector's own included -- and tracks its detections per camera id.  vph_udp_sync waits until at least
@@ -109,6 +115,10 @@ int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source);
 int vph_udp_open(VphDetector* d, const char* ip, int port);
 int vph_udp_send(VphDetector* d);
 int vph_udp_sync(VphDetector* d, int at_least, int timeout_ms);
+/* VisionSocket::geometryCheck + Perspective::geometryCheck (udpsocket.cpp:113-130, Perspective.cpp:35-125): waits up to timeout_ms for a
+ * geometry newer than the one last applied to arrive on the socket and derives the kernel scalars from it.  1 = applied, 0 = nothing
+ * new (or no calibration for this camera), < 0 = error.  Outputs as vph_apply_geometry_packet. */
+int vph_udp_apply_geometry(VphDetector* d, int img_w, int img_h, float resampling_factor, int timeout_ms, float* out_f, int32_t* out_i, VpCameraModel* out_model);
 int vph_udp_close(VphDetector* d);
 
 /* One step of `n` independent camera feeds (one detector each, e.g. the frames of one GPU launch group), on `threads` host

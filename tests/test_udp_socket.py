@@ -123,3 +123,31 @@ def test_foreign_and_malformed_datagrams_are_ignored():
     finally:
         tx.close()
         d.udp_close()
+
+
+def test_geometry_arrives_over_the_socket():
+    """A geometry publisher (ssl-vision, or python/geom_publisher.py of the reference) multicasts SSL_WrapperPacket{geometry}; the
+    receiver thread keeps the latest one and bumps a version when it differs (udpsocket.cpp:113-130,156-162); the frame loop then
+    derives the kernel scalars (Perspective::geometryCheck)."""
+    G = pytest.importorskip("test_geometry_packet")
+    port = _free_udp_port()
+    d = H.Detector()
+    d.udp_open("127.0.0.1", port)
+    tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    try:
+        assert d.udp_apply_geometry((64, 48), timeout_ms=50) is None  # nothing heard yet
+        pkt = G._packet(G.SMALL)
+        tx.sendto(pkt, ("127.0.0.1", port))
+        got = d.udp_apply_geometry((64, 48))
+        want = H.geometry_check(G.SMALL, 64, 48, 64, 48, (9000, 6000, 300, 250), resampling_factor=1.0)
+        assert got is not None and got["geometry_version"] == 1
+        assert G.bits(got["field_scale"]) == G.bits(want["field_scale"]) and np.array_equal(G.bits(got["extent"]), G.bits(want["extent"])) and bytes(got["model"]) == bytes(want["model"])
+        tx.sendto(pkt, ("127.0.0.1", port))  # the publisher repeats itself every few seconds: same content, no new version
+        assert d.udp_apply_geometry((64, 48), timeout_ms=200) is None
+        tx.sendto(G._packet(G.SMALL, goal_boundary=None), ("127.0.0.1", port))  # the field changed
+        got2 = d.udp_apply_geometry((64, 48))
+        want2 = H.geometry_check(G.SMALL, 64, 48, 64, 48, (9000, 6000, 300, -1), resampling_factor=1.0)
+        assert got2 is not None and got2["geometry_version"] == 2 and np.array_equal(G.bits(got2["extent"]), G.bits(want2["extent"]))
+    finally:
+        tx.close()
+        d.udp_close()

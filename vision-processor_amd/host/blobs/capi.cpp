@@ -11,6 +11,7 @@ struct VphDetector {
 	vp::BlobResources r;
 	vp::DetectionFrame frame;
 	std::unique_ptr<vp::VisionSocket> socket;
+	int socketGeometryApplied = 0; // version of the socket's geometry the perspective was last derived from
 };
 
 namespace {
@@ -307,6 +308,57 @@ int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, c
 	work();
 	for(std::thread& t : pool) t.join();
 	return VP_OK;
+}
+
+static int applyGeometry(VphDetector* d, const vp::FieldSize& field, const std::vector<vp::CameraCalibration>& calibs, int img_w, int img_h, float resampling_factor, float* out_f,
+		int32_t* out_i, VpCameraModel* out_model);
+
+int vph_apply_geometry_packet(VphDetector* d, const uint8_t* buf, int len, int img_w, int img_h, float resampling_factor, float* out_f, int32_t* out_i, VpCameraModel* out_model) {
+	if(!d || len < 0 || (len && !buf) || img_w <= 1 || img_h <= 1) return VP_ERR_INVALID;
+	vp::FieldSize field;
+	std::vector<vp::CameraCalibration> calibs;
+	bool has = false;
+	if(!vp::decodeGeometryPacket(buf, (size_t)len, field, calibs, has)) return VP_ERR_INVALID;
+	if(!has) return 0;
+	return applyGeometry(d, field, calibs, img_w, img_h, resampling_factor, out_f, out_i, out_model);
+}
+
+int vph_udp_apply_geometry(VphDetector* d, int img_w, int img_h, float resampling_factor, int timeout_ms, float* out_f, int32_t* out_i, VpCameraModel* out_model) {
+	if(!d || !d->socket || img_w <= 1 || img_h <= 1) return VP_ERR_INVALID;
+	if(!d->socket->waitForGeometry(d->socketGeometryApplied, timeout_ms)) return 0;
+	vp::FieldSize field;
+	std::vector<vp::CameraCalibration> calibs;
+	d->socketGeometryApplied = d->socket->getGeometryVersion();
+	d->socket->getGeometry(field, calibs);
+	return applyGeometry(d, field, calibs, img_w, img_h, resampling_factor, out_f, out_i, out_model);
+}
+
+static int applyGeometry(VphDetector* d, const vp::FieldSize& field, const std::vector<vp::CameraCalibration>& calibs, int img_w, int img_h, float resampling_factor, float* out_f,
+		int32_t* out_i, VpCameraModel* out_model) {
+	vp::Perspective& p = *d->r.perspective;
+	const int before = p.geometryVersion;
+	p.setGeometry(field, calibs.data(), (int)calibs.size());
+	p.geometryCheck(img_w, img_h, d->r.maxBotHeight, resampling_factor);
+	bool mine = false;
+	for(const vp::CameraCalibration& c : calibs) mine |= c.camera_id == (uint32_t)d->r.camId;
+	if(!mine || !p.geometryVersion || p.geometryVersion == before) return 0;
+	if(field.ball_radius > 0.f) d->r.ballRadius = field.ball_radius; // udpsocket.cpp:123-124 (has_ball_radius)
+	if(out_f) {
+		out_f[0] = p.fieldScale;
+		for(int i = 0; i < 4; i++) out_f[1 + i] = p.visibleFieldExtent[i];
+		out_f[5] = p.minBlobRadius;
+		out_f[6] = p.maxBlobRadius;
+	}
+	if(out_i) {
+		out_i[0] = p.reprojectedFieldSize.x;
+		out_i[1] = p.reprojectedFieldSize.y;
+		out_i[2] = p.gradOffset();
+		out_i[3] = p.circleRadius();
+		out_i[4] = p.listRadius();
+		out_i[5] = p.geometryVersion;
+	}
+	if(out_model) *out_model = p.getCLCameraModel();
+	return 1;
 }
 
 int vph_udp_open(VphDetector* d, const char* ip, int port) {

@@ -193,6 +193,10 @@ std::vector<uint8_t> encodeWrapperPacket(const DetectionFrame& detection);
 // and back (what VisionSocket::parse needs from a received packet: udpsocket.cpp:146-154); false on malformed input
 bool decodeWrapperPacket(const uint8_t* data, size_t size, DetectionFrame& detection, bool& hasDetection, int& source);
 
+// The geometry half of a wrapper packet (SSL_WrapperPacket.geometry = SSL_GeometryData: field size with its line segments and arcs,
+// one calibration per camera), reduced to the structs Perspective::setGeometry takes.  hasGeometry = the packet carried one.
+bool decodeGeometryPacket(const uint8_t* data, size_t size, FieldSize& field, std::vector<CameraCalibration>& calibs, bool& hasGeometry);
+
 // src/udpsocket.{h,cpp}:26-113 -- the datagram socket the wrapper packets travel on.  UDPSocket opens an IPv4 datagram socket
 // bound to (ip, port) with SO_REUSEADDR / SO_BROADCAST / multicast TTL 32, joins the group when ip is a multicast address, and
 // runs a receiver thread that hands every datagram to parse().  (The reference starts that thread in the base-class constructor,
@@ -229,6 +233,9 @@ public:
 	std::map<unsigned int, std::vector<TrackingState>> getTrackedObjects();       // udpsocket.cpp:132-137
 	int receivedPackets();                                                        // datagrams that carried a detection
 	bool waitForPackets(int atLeast, int timeoutMs);
+	int getGeometryVersion();                                                     // udpsocket.cpp:113-130: bumped when a different geometry arrives
+	void getGeometry(FieldSize& field, std::vector<CameraCalibration>& calibs);
+	bool waitForGeometry(int newerThan, int timeoutMs);
 
 protected:
 	void parse(const uint8_t* data, int length) override; // udpsocket.cpp:146-163 (detection part)

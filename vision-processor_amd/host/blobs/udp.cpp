@@ -94,11 +94,41 @@ void UDPSocket::run() {
 	}
 }
 
+namespace {
+bool sameBits(float a, float b) { return std::memcmp(&a, &b, sizeof(float)) == 0; }
+bool sameGeometry(const FieldSize& fa, const std::vector<CameraCalibration>& ca, const FieldSize& fb, const std::vector<CameraCalibration>& cb) {
+	if(fa.field_length != fb.field_length || fa.field_width != fb.field_width || fa.boundary_width != fb.boundary_width ||
+			fa.has_boundary_width_goal_line != fb.has_boundary_width_goal_line || fa.boundary_width_goal_line != fb.boundary_width_goal_line || fa.line_thickness != fb.line_thickness ||
+			!sameBits(fa.ball_radius, fb.ball_radius) || !sameBits(fa.max_robot_radius, fb.max_robot_radius) || fa.field_lines.size() != fb.field_lines.size() ||
+			fa.field_arcs.size() != fb.field_arcs.size() || ca.size() != cb.size())
+		return false;
+	for(size_t i = 0; i < fa.field_lines.size(); i++)
+		if(std::memcmp(&fa.field_lines[i], &fb.field_lines[i], sizeof(FieldLine)) != 0) return false;
+	for(size_t i = 0; i < fa.field_arcs.size(); i++)
+		if(std::memcmp(&fa.field_arcs[i], &fb.field_arcs[i], sizeof(FieldArc)) != 0) return false;
+	for(size_t i = 0; i < ca.size(); i++) {
+		const CameraCalibration &a = ca[i], &b = cb[i];
+		const float av[14] = {a.focal_length, a.principal_point_x, a.principal_point_y, a.distortion, a.q0, a.q1, a.q2, a.q3, a.tx, a.ty, a.tz, a.derived_camera_world_tx,
+				a.derived_camera_world_ty, a.derived_camera_world_tz};
+		const float bv[14] = {b.focal_length, b.principal_point_x, b.principal_point_y, b.distortion, b.q0, b.q1, b.q2, b.q3, b.tx, b.ty, b.tz, b.derived_camera_world_tx,
+				b.derived_camera_world_ty, b.derived_camera_world_tz};
+		if(a.camera_id != b.camera_id || a.has_derived != b.has_derived || a.pixel_image_width != b.pixel_image_width || a.pixel_image_height != b.pixel_image_height ||
+				std::memcmp(av, bv, sizeof(av)) != 0)
+			return false;
+	}
+	return true;
+}
+} // namespace
+
 struct VisionSocket::State {
 	std::mutex m;
 	std::condition_variable cv;
 	BlobResources tracker; // only trackedObjects and ballRadius are used (detectionTracking's working set)
 	int received = 0;
+	// the last geometry heard on the group (udpsocket.cpp:156-162) and how often it changed (getGeometryVersion, :113-130)
+	FieldSize field;
+	std::vector<CameraCalibration> calibs;
+	int geometryVersion = 0;
 };
 
 VisionSocket::VisionSocket(const std::string& ip, uint16_t port, int camId, float defaultBotHeight): UDPSocket(ip, port), state(new State()), camId(camId) {
@@ -118,14 +148,40 @@ void VisionSocket::send(const DetectionFrame& detection) {
 
 void VisionSocket::parse(const uint8_t* data, int length) {
 	DetectionFrame frame;
-	bool hasDetection = false;
+	bool hasDetection = false, hasGeometry = false;
 	int source = 0;
 	if(!decodeWrapperPacket(data, (size_t)length, frame, hasDetection, source)) return; // ParseFromArray failure: dropped (udpsocket.cpp:147-148)
-	if(!hasDetection) return;
+	FieldSize field;
+	std::vector<CameraCalibration> calibs;
+	if(!decodeGeometryPacket(data, (size_t)length, field, calibs, hasGeometry)) return;
 	std::lock_guard<std::mutex> lock(state->m);
-	detectionTracking(state->tracker, frame);
-	state->received++;
+	if(hasDetection) {
+		detectionTracking(state->tracker, frame);
+		state->received++;
+	}
+	if(hasGeometry && !sameGeometry(field, calibs, state->field, state->calibs)) { // MessageDifferencer::Equals on the fields this path reads (:157)
+		state->field = field;
+		state->calibs = calibs;
+		state->geometryVersion++;
+		if(field.ball_radius > 0.f) state->tracker.ballRadius = field.ball_radius; // :123-124
+	}
 	state->cv.notify_all();
+}
+
+int VisionSocket::getGeometryVersion() {
+	std::lock_guard<std::mutex> lock(state->m);
+	return state->geometryVersion;
+}
+
+void VisionSocket::getGeometry(FieldSize& field, std::vector<CameraCalibration>& calibs) {
+	std::lock_guard<std::mutex> lock(state->m);
+	field = state->field;
+	calibs = state->calibs;
+}
+
+bool VisionSocket::waitForGeometry(int newerThan, int timeoutMs) {
+	std::unique_lock<std::mutex> lock(state->m);
+	return state->cv.wait_for(lock, std::chrono::milliseconds(timeoutMs), [&] { return state->geometryVersion > newerThan; });
 }
 
 std::map<unsigned int, std::vector<TrackingState>> VisionSocket::getTrackedObjects() {

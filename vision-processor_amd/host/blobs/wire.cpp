@@ -204,7 +204,119 @@ bool decodeFrame(Reader r, DetectionFrame& d) {
 	return r.ok;
 }
 
+// ---- SSL_GeometryData (proto/ssl_vision_geometry.proto:3-99): the fields Perspective / CameraModel / the hypothesis stage read ----
+bool decodeVector2f(Reader r, Vec2f& v) {
+	v = {};
+	while(r.ok && !r.done()) {
+		const uint64_t t = r.varint();
+		const int field = (int)(t >> 3), type = (int)(t & 7);
+		if(type == I32 && field == 1) v.x = r.f32();
+		else if(type == I32 && field == 2) v.y = r.f32();
+		else r.skip(type);
+	}
+	return r.ok;
+}
+
+bool decodeFieldSize(Reader r, FieldSize& f) {
+	f = FieldSize();
+	f.ball_radius = 0.f; // proto2 optionals without a default read as zero when absent (Perspective.cpp:69-70 takes them as they come)
+	f.max_robot_radius = 0.f;
+	while(r.ok && !r.done()) {
+		const uint64_t t = r.varint();
+		const int field = (int)(t >> 3), type = (int)(t & 7);
+		if(type == VARINT && field == 1) f.field_length = (int32_t)r.varint();
+		else if(type == VARINT && field == 2) f.field_width = (int32_t)r.varint();
+		else if(type == VARINT && field == 5) f.boundary_width = (int32_t)r.varint();
+		else if(type == VARINT && field == 16) {
+			f.has_boundary_width_goal_line = true;
+			f.boundary_width_goal_line = (int32_t)r.varint();
+		} else if(type == VARINT && field == 11) f.line_thickness = (int32_t)r.varint();
+		else if(type == I32 && field == 14) f.ball_radius = r.f32();
+		else if(type == I32 && field == 15) f.max_robot_radius = r.f32();
+		else if(type == LEN && field == 6) { // SSL_FieldLineSegment: p1 = 2, p2 = 3
+			Reader m = r.sub();
+			FieldLine line;
+			while(m.ok && !m.done()) {
+				const uint64_t mt = m.varint();
+				const int mf = (int)(mt >> 3), my = (int)(mt & 7);
+				if(my == LEN && mf == 2) {
+					if(!decodeVector2f(m.sub(), line.p1)) return false;
+				} else if(my == LEN && mf == 3) {
+					if(!decodeVector2f(m.sub(), line.p2)) return false;
+				} else m.skip(my);
+			}
+			if(!m.ok) return false;
+			f.field_lines.push_back(line);
+		} else if(type == LEN && field == 7) { // SSL_FieldCircularArc: center = 2, radius = 3, a1 = 4, a2 = 5
+			Reader m = r.sub();
+			FieldArc arc;
+			while(m.ok && !m.done()) {
+				const uint64_t mt = m.varint();
+				const int mf = (int)(mt >> 3), my = (int)(mt & 7);
+				if(my == LEN && mf == 2) {
+					if(!decodeVector2f(m.sub(), arc.center)) return false;
+				} else if(my == I32 && mf == 3) arc.radius = m.f32();
+				else if(my == I32 && mf == 4) arc.a1 = m.f32();
+				else if(my == I32 && mf == 5) arc.a2 = m.f32();
+				else m.skip(my);
+			}
+			if(!m.ok) return false;
+			f.field_arcs.push_back(arc);
+		} else r.skip(type); // goal sizes, penalty area, centre circle radius ...: not read on this path
+	}
+	return r.ok;
+}
+
+bool decodeCalibration(Reader r, CameraCalibration& c) {
+	c = CameraCalibration();
+	int derived = 0;
+	while(r.ok && !r.done()) {
+		const uint64_t t = r.varint();
+		const int field = (int)(t >> 3), type = (int)(t & 7);
+		if(type == VARINT && field == 1) c.camera_id = (uint32_t)r.varint();
+		else if(type == VARINT && field == 16) c.pixel_image_width = (uint32_t)r.varint();
+		else if(type == VARINT && field == 17) c.pixel_image_height = (uint32_t)r.varint();
+		else if(type == I32 && field >= 2 && field <= 15) {
+			const float v = r.f32();
+			float* slots[14] = {&c.focal_length, &c.principal_point_x, &c.principal_point_y, &c.distortion, &c.q0, &c.q1, &c.q2, &c.q3, &c.tx, &c.ty, &c.tz,
+					&c.derived_camera_world_tx, &c.derived_camera_world_ty, &c.derived_camera_world_tz};
+			*slots[field - 2] = v;
+			if(field >= 13) derived |= 1 << (field - 13);
+		} else r.skip(type);
+	}
+	c.has_derived = derived == 7; // Perspective.cpp:45: all three derived_camera_world_* present
+	return r.ok;
+}
+
 } // namespace
+
+bool decodeGeometryPacket(const uint8_t* data, size_t size, FieldSize& field, std::vector<CameraCalibration>& calibs, bool& hasGeometry) {
+	Reader r{data, data + size};
+	hasGeometry = false;
+	calibs.clear();
+	while(r.ok && !r.done()) {
+		const uint64_t t = r.varint();
+		const int fieldNo = (int)(t >> 3), type = (int)(t & 7);
+		if(type == LEN && fieldNo == 2) { // SSL_WrapperPacket.geometry
+			Reader g = r.sub();
+			calibs.clear();
+			while(g.ok && !g.done()) {
+				const uint64_t gt = g.varint();
+				const int gf = (int)(gt >> 3), gy = (int)(gt & 7);
+				if(gy == LEN && gf == 1) {
+					if(!decodeFieldSize(g.sub(), field)) return false;
+				} else if(gy == LEN && gf == 2) {
+					CameraCalibration c;
+					if(!decodeCalibration(g.sub(), c)) return false;
+					calibs.push_back(c);
+				} else g.skip(gy); // models
+			}
+			if(!g.ok) return false;
+			hasGeometry = true;
+		} else r.skip(type);
+	}
+	return r.ok;
+}
 
 std::vector<uint8_t> encodeWrapperPacket(const DetectionFrame& detection) {
 	Writer w;

@@ -221,6 +221,19 @@ class Detector:
     def track(self):
         assert self.l.vph_track(self.h) == 0
 
+    def apply_geometry_packet(self, data: bytes, img_size, resampling_factor=1.0):
+        """VisionSocket::parse + Perspective::geometryCheck for an SSL_WrapperPacket carrying geometry.  Returns None when the packet has
+        no geometry (or no calibration for this camera), else the kernel scalars as geometry_check() returns them."""
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data.ljust(1, b"\0"))
+        of, oi, m = (C.c_float * 7)(), (C.c_int32 * 6)(), VpCameraModel()
+        rc = self.l.vph_apply_geometry_packet(self.h, buf, len(data), int(img_size[0]), int(img_size[1]), C.c_float(resampling_factor), of, oi, C.byref(m))
+        if rc < 0:
+            raise ValueError("malformed SSL_WrapperPacket")
+        if rc == 0:
+            return None
+        return {"field_scale": of[0], "extent": [of[1], of[2], of[3], of[4]], "min_blob_radius": of[5], "max_blob_radius": of[6],
+                "fw": oi[0], "fh": oi[1], "grad_offset": oi[2], "circle_radius": oi[3], "list_radius": oi[4], "geometry_version": oi[5], "model": m}
+
     def udp_open(self, ip: str, port: int):
         rc = self.l.vph_udp_open(self.h, ip.encode(), int(port))
         if rc != 0:
@@ -232,6 +245,17 @@ class Detector:
     def udp_sync(self, at_least: int, timeout_ms: int = 2000) -> int:
         """Waits for `at_least` received detection packets; installs the socket's tracked objects; returns the count (-1 = timeout)."""
         return int(self.l.vph_udp_sync(self.h, int(at_least), int(timeout_ms)))
+
+    def udp_apply_geometry(self, img_size, resampling_factor=1.0, timeout_ms=2000):
+        """Waits for a geometry newer than the last applied one on the socket and derives the kernel scalars from it (None = nothing new)."""
+        of, oi, m = (C.c_float * 7)(), (C.c_int32 * 6)(), VpCameraModel()
+        rc = self.l.vph_udp_apply_geometry(self.h, int(img_size[0]), int(img_size[1]), C.c_float(resampling_factor), int(timeout_ms), of, oi, C.byref(m))
+        if rc < 0:
+            raise OSError(f"vph_udp_apply_geometry failed: {rc}")
+        if rc == 0:
+            return None
+        return {"field_scale": of[0], "extent": [of[1], of[2], of[3], of[4]], "min_blob_radius": of[5], "max_blob_radius": of[6],
+                "fw": oi[0], "fh": oi[1], "grad_offset": oi[2], "circle_radius": oi[3], "list_radius": oi[4], "geometry_version": oi[5], "model": m}
 
     def udp_close(self):
         self.l.vph_udp_close(self.h)
