@@ -119,6 +119,10 @@ int vph_udp_sync(VphDetector* d, int at_least, int timeout_ms);
  * geometry newer than the one last applied to arrive on the socket and derives the kernel scalars from it.  1 = applied, 0 = nothing
  * new (or no calibration for this camera), < 0 = error.  Outputs as vph_apply_geometry_packet. */
 int vph_udp_apply_geometry(VphDetector* d, int img_w, int img_h, float resampling_factor, int timeout_ms, float* out_f, int32_t* out_i, VpCameraModel* out_model);
+/* VisionSocket::updateTime + getReceivedOffsets (udpsocket.cpp:139-144,259-282; main.cpp:361-362,371): steers the socket's clock by
+ * half the mean offset asymmetry against the other cameras, installs the received offsets as the t_offsets of the detector's next
+ * frames, returns the clock (system time + accumulated offset, seconds) in *now. */
+int vph_udp_update_time(VphDetector* d, double* now);
 int vph_udp_close(VphDetector* d);
 
 /* One step of `n` independent camera feeds (one detector each, e.g. the frames of one GPU launch group), on `threads` host

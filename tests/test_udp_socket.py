@@ -151,3 +151,40 @@ def test_geometry_arrives_over_the_socket():
     finally:
         tx.close()
         d.udp_close()
+
+
+def test_clock_offsets_between_cameras():
+    """timeSynchronization / updateTime (udpsocket.cpp:259-302): camera 0 hears camera 2, whose clock runs 50 ms ahead and which
+    reports back the offset it measured against camera 0; the received offset lands in the next frame's t_offsets and the local clock
+    is steered by half the asymmetry; a large backward step is refused."""
+    import time
+    port = _free_udp_port()
+    d, _ = S.make_pair(S.NADIR, cam_id=0)
+    other, _ = S.make_pair(S.NADIR, cam_id=2)
+    d.udp_open("127.0.0.1", port)
+    tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    arr, _, _ = S.scene(95)
+    try:
+        def hear(t_sent_skew, reported):
+            other.set_offsets(reported)
+            other.detect(arr, 1, 1.0)
+            other.set_t_sent(time.time() + t_sent_skew)
+            n = d.udp_sync(0, 10)
+            tx.sendto(other.encode(), ("127.0.0.1", port))
+            assert d.udp_sync(max(n, 0) + 1, 3000) == max(n, 0) + 1
+
+        t0 = d.udp_update_time()
+        assert abs(t0 - time.time()) < 0.05  # nothing heard yet: plain system time
+        hear(0.050, [0.010])                  # other.t_sent - local time = +50 ms; it saw us 10 ms ahead of itself
+        t1 = d.udp_update_time()
+        fr = d.detect(arr, 2, 2.0)
+        offs = fr["t_offsets"]
+        assert len(offs) == 3 and offs[0] == 0 and offs[1] == 0 and abs(offs[2] - 0.050) < 0.02  # indexed by sender id
+        # offset = (received - sent) / (2 * cams) = (0.050 - 0.010) / 6, applied once
+        assert abs((t1 - time.time()) - (0.040 / 6)) < 0.01
+        hear(-0.500, [0.0])                   # a 500 ms backward step: refused (offset < -10 ms)
+        t2 = d.udp_update_time()
+        assert abs((t2 - time.time()) - (0.040 / 6)) < 0.01
+    finally:
+        tx.close()
+        d.udp_close()

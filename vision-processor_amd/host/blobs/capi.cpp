@@ -384,6 +384,14 @@ int vph_udp_sync(VphDetector* d, int at_least, int timeout_ms) {
 	return d->socket->receivedPackets();
 }
 
+int vph_udp_update_time(VphDetector* d, double* now) {
+	if(!d || !d->socket) return VP_ERR_INVALID;
+	d->r.receivedOffsets = d->socket->getReceivedOffsets(); // main.cpp:361-362
+	d->socket->updateTime();                                 // main.cpp:371
+	if(now) *now = d->socket->getRealTime();
+	return VP_OK;
+}
+
 int vph_udp_close(VphDetector* d) {
 	if(!d) return VP_ERR_INVALID;
 	d->socket.reset();

@@ -233,6 +233,9 @@ public:
 	std::map<unsigned int, std::vector<TrackingState>> getTrackedObjects();       // udpsocket.cpp:132-137
 	int receivedPackets();                                                        // datagrams that carried a detection
 	bool waitForPackets(int atLeast, int timeoutMs);
+	std::vector<float> getReceivedOffsets();                                      // udpsocket.cpp:139-144: other.t_sent - local time, per sender id
+	double updateTime();                                                          // udpsocket.cpp:259-282: steers the clock offset, returns it
+	double getRealTime();                                                         // cameradriver.cpp:25-27: system clock + offset
 	int getGeometryVersion();                                                     // udpsocket.cpp:113-130: bumped when a different geometry arrives
 	void getGeometry(FieldSize& field, std::vector<CameraCalibration>& calibs);
 	bool waitForGeometry(int newerThan, int timeoutMs);
@@ -244,6 +247,7 @@ private:
 	struct State;
 	State* state;
 	const int camId;
+	double getRealTimeLocked() const;
 };
 
 } // namespace vp

@@ -129,6 +129,10 @@ struct VisionSocket::State {
 	FieldSize field;
 	std::vector<CameraCalibration> calibs;
 	int geometryVersion = 0;
+	// clock offsets against the other cameras (udpsocket.h:109-112): [sender id]
+	std::vector<float> sentOffsets;     // local.t_sent - other.time, as the other camera reported it back in its t_offsets
+	std::vector<float> receivedOffsets; // other.t_sent - local.time
+	double realTimeOffset = 0.0;        // cameradriver.cpp:24: what updateTime() steers
 };
 
 VisionSocket::VisionSocket(const std::string& ip, uint16_t port, int camId, float defaultBotHeight): UDPSocket(ip, port), state(new State()), camId(camId) {
@@ -156,6 +160,18 @@ void VisionSocket::parse(const uint8_t* data, int length) {
 	if(!decodeGeometryPacket(data, (size_t)length, field, calibs, hasGeometry)) return;
 	std::lock_guard<std::mutex> lock(state->m);
 	if(hasDetection) {
+		{ // timeSynchronization (udpsocket.cpp:284-302)
+			const double localTime = getRealTimeLocked();
+			const unsigned senderId = frame.camera_id;
+			if(senderId < 4096) { // a camera id is a small index; a garbage id must not size the vectors
+				while(state->receivedOffsets.size() <= senderId) {
+					state->receivedOffsets.push_back(0.0f);
+					state->sentOffsets.push_back(0.0f);
+				}
+				state->receivedOffsets[senderId] = (float)(frame.t_sent - localTime);
+				if(frame.t_offsets.size() > (size_t)camId) state->sentOffsets[senderId] = frame.t_offsets[(size_t)camId];
+			}
+		}
 		detectionTracking(state->tracker, frame);
 		state->received++;
 	}
@@ -166,6 +182,38 @@ void VisionSocket::parse(const uint8_t* data, int length) {
 		if(field.ball_radius > 0.f) state->tracker.ballRadius = field.ball_radius; // :123-124
 	}
 	state->cv.notify_all();
+}
+
+double VisionSocket::getRealTimeLocked() const { // cameradriver.cpp:25-27
+	return (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::system_clock::now().time_since_epoch()).count() / 1e6 + state->realTimeOffset;
+}
+
+double VisionSocket::getRealTime() {
+	std::lock_guard<std::mutex> lock(state->m);
+	return getRealTimeLocked();
+}
+
+std::vector<float> VisionSocket::getReceivedOffsets() { // udpsocket.cpp:139-144
+	std::lock_guard<std::mutex> lock(state->m);
+	return state->receivedOffsets;
+}
+
+double VisionSocket::updateTime() { // udpsocket.cpp:259-282: half the mean asymmetry of the offsets, backward jumps beyond 10 ms refused
+	std::lock_guard<std::mutex> lock(state->m);
+	double offset = 0.0;
+	const int cams = (int)state->receivedOffsets.size();
+	for(int cam = 0; cam < cams; cam++) {
+		if(cam == camId) continue; // not against itself
+		offset += state->receivedOffsets[cam] - state->sentOffsets[cam];
+	}
+	if(cams == 0) return state->realTimeOffset;
+	offset /= 2 * cams;
+	if(offset < -0.010) {
+		fprintf(stderr, "[WARN] vision socket: backward clock step of %f s refused\n", offset);
+		return state->realTimeOffset;
+	}
+	state->realTimeOffset += offset;
+	return state->realTimeOffset;
 }
 
 int VisionSocket::getGeometryVersion() {

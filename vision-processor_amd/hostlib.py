@@ -257,6 +257,12 @@ class Detector:
         return {"field_scale": of[0], "extent": [of[1], of[2], of[3], of[4]], "min_blob_radius": of[5], "max_blob_radius": of[6],
                 "fw": oi[0], "fh": oi[1], "grad_offset": oi[2], "circle_radius": oi[3], "list_radius": oi[4], "geometry_version": oi[5], "model": m}
 
+    def udp_update_time(self) -> float:
+        """VisionSocket::updateTime; the received clock offsets become the t_offsets of the next frames.  Returns the socket's clock."""
+        now = C.c_double(0)
+        assert self.l.vph_udp_update_time(self.h, C.byref(now)) == 0
+        return now.value
+
     def udp_close(self):
         self.l.vph_udp_close(self.h)
 
