@@ -125,6 +125,14 @@ int vph_udp_apply_geometry(VphDetector* d, int img_w, int img_h, float resamplin
 int vph_udp_update_time(VphDetector* d, double* now);
 int vph_udp_close(VphDetector* d);
 
+/* GCSocket (udpsocket.cpp:304-330): robot heights per team colour from game-controller Referee packets.  names / heights_mm: the
+ * height table (the reference ships robot-heights.yml); the detector's maxBotHeight / defaultBotHeight / yellow / blue heights are
+ * set from it at once, and vph_gc_sync (waits for at_least packets, -1 on timeout) installs the heights of the teams the referee
+ * named.  NB maxBotHeight also enters the GPU path (resampling plane, Resources.cpp:159): re-derive the geometry after it changes. */
+int vph_gc_open(VphDetector* d, const char* ip, int port, const char* const* names, const double* heights_mm, int n);
+int vph_gc_sync(VphDetector* d, int at_least, int timeout_ms, double heights_out[4] /* max, default, yellow, blue */);
+int vph_gc_close(VphDetector* d);
+
 /* One step of `n` independent camera feeds (one detector each, e.g. the frames of one GPU launch group), on `threads` host
  * threads: per feed the read-back of main.cpp:297-317 (min(max_matches, counter[0]) records of its slice, flat2field), vph_detect,
  * t_sent, the loop-back of its own packet into its tracker, and the encoded SSL_WrapperPacket into packets + i * packet_cap

@@ -188,3 +188,57 @@ def test_clock_offsets_between_cameras():
     finally:
         tx.close()
         d.udp_close()
+
+
+def test_game_controller_referee_sets_the_robot_heights():
+    """GCSocket (udpsocket.cpp:304-330): the height table gives maxBotHeight (its maximum) and the default (its mean); a Referee packet
+    naming listed teams switches the per-colour heights, which the detection frame then reports (hypothesis.cpp:141-149)."""
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    T = descriptor_pb2.FieldDescriptorProto
+    f = descriptor_pb2.FileDescriptorProto(name="vp_test_referee.proto", syntax="proto2")
+    ti = f.message_type.add(name="TeamInfo")  # proto/ssl_gc_referee_message.proto:119-150 (the fields needed to build a valid packet)
+    for name, num, typ in (("name", 1, T.TYPE_STRING), ("score", 2, T.TYPE_UINT32), ("red_cards", 3, T.TYPE_UINT32), ("yellow_cards", 5, T.TYPE_UINT32),
+                           ("timeouts", 6, T.TYPE_UINT32), ("timeout_time", 7, T.TYPE_UINT32), ("goalkeeper", 8, T.TYPE_UINT32)):
+        ti.field.add(name=name, number=num, label=T.LABEL_REQUIRED, type=typ)
+    ref = f.message_type.add(name="Referee")  # :152-157
+    for name, num, typ, tn in (("packet_timestamp", 1, T.TYPE_UINT64, None), ("stage", 2, T.TYPE_INT32, None), ("command", 4, T.TYPE_INT32, None),
+                               ("command_counter", 5, T.TYPE_UINT32, None), ("command_timestamp", 6, T.TYPE_UINT64, None), ("yellow", 7, T.TYPE_MESSAGE, ".TeamInfo"),
+                               ("blue", 8, T.TYPE_MESSAGE, ".TeamInfo")):
+        fd = ref.field.add(name=name, number=num, label=T.LABEL_REQUIRED, type=typ)
+        if tn:
+            fd.type_name = tn
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    Referee = message_factory.GetMessageClass(pool.FindMessageTypeByName("Referee"))
+
+    def referee(yellow, blue):
+        m = Referee()
+        m.packet_timestamp, m.stage, m.command, m.command_counter, m.command_timestamp = 1, 0, 0, 7, 2
+        for team, name in ((m.yellow, yellow), (m.blue, blue)):
+            team.name, team.score, team.red_cards, team.yellow_cards, team.timeouts, team.timeout_time, team.goalkeeper = name, 0, 0, 0, 4, 300000000, 0
+        return m.SerializeToString()
+
+    heights = {"TIGERs Mannheim": 143.0, "ER-Force": 148.0, "Robocup Junior SSL Team": 180.0, "ibis": 90.0}
+    port = _free_udp_port()
+    d, _ = S.make_pair(S.NADIR)
+    d.gc_open("127.0.0.1", port, heights)
+    tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    try:
+        n, h = d.gc_sync(0, 10)
+        assert h == {"max": 180.0, "default": (143.0 + 148.0 + 180.0 + 90.0) / 4, "yellow": 140.25, "blue": 140.25}
+        tx.sendto(referee("TIGERs Mannheim", "ibis"), ("127.0.0.1", port))
+        n, h = d.gc_sync(1, 3000)
+        assert n == 1 and h["yellow"] == 143.0 and h["blue"] == 90.0 and h["max"] == 180.0
+        tx.sendto(referee("Unknown Team", "ER-Force"), ("127.0.0.1", port))  # an unlisted name leaves that colour alone
+        n, h = d.gc_sync(2, 3000)
+        assert n == 2 and h["yellow"] == 143.0 and h["blue"] == 148.0
+        tx.sendto(b"\\x3a\\x05\\x0a\\x09", ("127.0.0.1", port))  # truncated TeamInfo: dropped
+        assert d.gc_sync(3, 200)[0] == -1
+        arr, _, _ = S.scene(96, n_robots=4, n_balls=1, n_clutter=0)
+        fr = d.detect(arr, 1, 1.0)
+        assert len(fr["robots_yellow"]) == 2 and len(fr["robots_blue"]) == 2
+        assert all(b["height"] == np.float32(143.0) for b in fr["robots_yellow"]) and all(b["height"] == np.float32(148.0) for b in fr["robots_blue"])
+    finally:
+        tx.close()
+        d.gc_close()

@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <map>
+#include <string>
 #include <thread>
 
 #include "detection.h"
@@ -11,6 +13,7 @@ struct VphDetector {
 	vp::BlobResources r;
 	vp::DetectionFrame frame;
 	std::unique_ptr<vp::VisionSocket> socket;
+	std::unique_ptr<vp::GCSocket> gcSocket;
 	int socketGeometryApplied = 0; // version of the socket's geometry the perspective was last derived from
 };
 
@@ -389,6 +392,41 @@ int vph_udp_update_time(VphDetector* d, double* now) {
 	d->r.receivedOffsets = d->socket->getReceivedOffsets(); // main.cpp:361-362
 	d->socket->updateTime();                                 // main.cpp:371
 	if(now) *now = d->socket->getRealTime();
+	return VP_OK;
+}
+
+int vph_gc_open(VphDetector* d, const char* ip, int port, const char* const* names, const double* heights_mm, int n) {
+	if(!d || !ip || port <= 0 || port > 65535 || n <= 0 || !names || !heights_mm) return VP_ERR_INVALID;
+	std::map<std::string, double> table;
+	for(int i = 0; i < n; i++) {
+		if(!names[i]) return VP_ERR_INVALID;
+		table[names[i]] = heights_mm[i];
+	}
+	d->gcSocket = std::make_unique<vp::GCSocket>(ip, (uint16_t)port, table);
+	if(!d->gcSocket->ok()) {
+		d->gcSocket.reset();
+		return VP_ERR_INVALID;
+	}
+	d->gcSocket->heights(d->r.maxBotHeight, d->r.defaultBotHeight, d->r.yellowBotHeight, d->r.blueBotHeight);
+	return VP_OK;
+}
+
+int vph_gc_sync(VphDetector* d, int at_least, int timeout_ms, double heights_out[4]) {
+	if(!d || !d->gcSocket) return VP_ERR_INVALID;
+	const bool ok = d->gcSocket->waitForPackets(at_least, timeout_ms);
+	d->gcSocket->heights(d->r.maxBotHeight, d->r.defaultBotHeight, d->r.yellowBotHeight, d->r.blueBotHeight);
+	if(heights_out) {
+		heights_out[0] = d->r.maxBotHeight;
+		heights_out[1] = d->r.defaultBotHeight;
+		heights_out[2] = d->r.yellowBotHeight;
+		heights_out[3] = d->r.blueBotHeight;
+	}
+	return ok ? d->gcSocket->receivedPackets() : -1;
+}
+
+int vph_gc_close(VphDetector* d) {
+	if(!d) return VP_ERR_INVALID;
+	d->gcSocket.reset();
 	return VP_OK;
 }
 

@@ -223,6 +223,28 @@ private:
 	Impl* impl = nullptr;
 };
 
+// The two team names of a game-controller Referee packet (what GCSocket::parse reads, udpsocket.cpp:317-330)
+bool decodeRefereeTeams(const uint8_t* data, size_t size, std::string& yellow, std::string& blue);
+
+// GCSocket (udpsocket.h:115-133, udpsocket.cpp:304-330): robot heights per team.  The height table (team name -> mm, the reference's
+// robot-heights.yml) comes from the caller; maxBotHeight is its maximum, defaultBotHeight its mean, and a Referee packet naming a
+// listed team switches that colour's height.
+class GCSocket: public UDPSocket {
+public:
+	GCSocket(const std::string& ip, uint16_t port, const std::map<std::string, double>& botHeights);
+	~GCSocket() override;
+	void heights(double& maxBotHeight, double& defaultBotHeight, double& yellowBotHeight, double& blueBotHeight);
+	int receivedPackets();
+	bool waitForPackets(int atLeast, int timeoutMs);
+
+protected:
+	void parse(const uint8_t* data, int length) override;
+
+private:
+	struct State;
+	State* state;
+};
+
 // VisionSocket (udpsocket.h:67-113), the part on this path: send the frame's SSL_WrapperPacket, receive everybody's (including
 // its own, the group loops back) and keep per-camera tracked objects for the next frame's tracked hypotheses.
 class VisionSocket: public UDPSocket {

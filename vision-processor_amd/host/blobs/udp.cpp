@@ -10,7 +10,9 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "detection.h"
@@ -92,6 +94,59 @@ void UDPSocket::run() {
 		}
 		parse(msgbuf.data(), (int)bytesRead);
 	}
+}
+
+struct GCSocket::State {
+	std::mutex m;
+	std::condition_variable cv;
+	std::map<std::string, double> botHeights;
+	double maxBotHeight = 0, defaultBotHeight = 0, yellowBotHeight = 0, blueBotHeight = 0;
+	int received = 0;
+};
+
+GCSocket::GCSocket(const std::string& ip, uint16_t port, const std::map<std::string, double>& botHeights): UDPSocket(ip, port), state(new State()) {
+	state->botHeights = botHeights;
+	for(const auto& entry : botHeights) { // udpsocket.cpp:304-314
+		if(entry.second > state->maxBotHeight) state->maxBotHeight = entry.second;
+		state->defaultBotHeight += entry.second;
+	}
+	if(!botHeights.empty()) state->defaultBotHeight /= (double)botHeights.size();
+	state->yellowBotHeight = state->blueBotHeight = state->defaultBotHeight;
+	start();
+}
+
+GCSocket::~GCSocket() {
+	stop();
+	delete state;
+}
+
+void GCSocket::parse(const uint8_t* data, int length) {
+	std::string yellow, blue;
+	if(!decodeRefereeTeams(data, (size_t)length, yellow, blue)) return;
+	std::lock_guard<std::mutex> lock(state->m);
+	const auto y = state->botHeights.find(yellow), b = state->botHeights.find(blue);
+	if(y != state->botHeights.end() && y->second != state->yellowBotHeight) state->yellowBotHeight = y->second;
+	if(b != state->botHeights.end() && b->second != state->blueBotHeight) state->blueBotHeight = b->second;
+	state->received++;
+	state->cv.notify_all();
+}
+
+void GCSocket::heights(double& maxBotHeight, double& defaultBotHeight, double& yellowBotHeight, double& blueBotHeight) {
+	std::lock_guard<std::mutex> lock(state->m);
+	maxBotHeight = state->maxBotHeight;
+	defaultBotHeight = state->defaultBotHeight;
+	yellowBotHeight = state->yellowBotHeight;
+	blueBotHeight = state->blueBotHeight;
+}
+
+int GCSocket::receivedPackets() {
+	std::lock_guard<std::mutex> lock(state->m);
+	return state->received;
+}
+
+bool GCSocket::waitForPackets(int atLeast, int timeoutMs) {
+	std::unique_lock<std::mutex> lock(state->m);
+	return state->cv.wait_for(lock, std::chrono::milliseconds(timeoutMs), [&] { return state->received >= atLeast; });
 }
 
 namespace {

@@ -6,6 +6,7 @@
 // (main.cpp:345-362, hypothesis.cpp:69-80,140-153) -- known fields in field-number order, `repeated float t_offsets` unpacked
 // (proto2 default).  tests/test_wire_format.py compares against google.protobuf (python) built from the same schema.
 #include <cstring>
+#include <string>
 
 #include "detection.h"
 
@@ -313,6 +314,32 @@ bool decodeGeometryPacket(const uint8_t* data, size_t size, FieldSize& field, st
 			}
 			if(!g.ok) return false;
 			hasGeometry = true;
+		} else r.skip(type);
+	}
+	return r.ok;
+}
+
+// Referee (proto/ssl_gc_referee_message.proto:119-157): the two team names, all GCSocket::parse reads (udpsocket.cpp:317-330)
+bool decodeRefereeTeams(const uint8_t* data, size_t size, std::string& yellow, std::string& blue) {
+	Reader r{data, data + size};
+	yellow.clear();
+	blue.clear();
+	while(r.ok && !r.done()) {
+		const uint64_t t = r.varint();
+		const int field = (int)(t >> 3), type = (int)(t & 7);
+		if(type == LEN && (field == 7 || field == 8)) { // TeamInfo yellow = 7, blue = 8; name = 1
+			Reader team = r.sub();
+			std::string& name = field == 7 ? yellow : blue;
+			while(team.ok && !team.done()) {
+				const uint64_t tt = team.varint();
+				const int tf = (int)(tt >> 3), ty = (int)(tt & 7);
+				if(ty == LEN && tf == 1) {
+					Reader n = team.sub();
+					if(!n.ok) return false;
+					name.assign(reinterpret_cast<const char*>(n.p), (size_t)(n.end - n.p));
+				} else team.skip(ty);
+			}
+			if(!team.ok) return false;
 		} else r.skip(type);
 	}
 	return r.ok;

@@ -263,6 +263,24 @@ class Detector:
         assert self.l.vph_udp_update_time(self.h, C.byref(now)) == 0
         return now.value
 
+    def gc_open(self, ip: str, port: int, bot_heights: dict):
+        """GCSocket: bot_heights = {team name: robot height in mm} (the reference's robot-heights.yml)."""
+        names = [k.encode() for k in bot_heights]
+        arr = (C.c_char_p * len(names))(*names)
+        hs = (C.c_double * len(names))(*[float(v) for v in bot_heights.values()])
+        rc = self.l.vph_gc_open(self.h, ip.encode(), int(port), arr, hs, len(names))
+        if rc != 0:
+            raise OSError(f"vph_gc_open({ip}:{port}) failed: {rc}")
+
+    def gc_sync(self, at_least: int, timeout_ms: int = 2000):
+        """Returns (packets received or -1 on timeout, {max, default, yellow, blue} heights now in force)."""
+        out = (C.c_double * 4)()
+        n = int(self.l.vph_gc_sync(self.h, int(at_least), int(timeout_ms), out))
+        return n, {"max": out[0], "default": out[1], "yellow": out[2], "blue": out[3]}
+
+    def gc_close(self):
+        self.l.vph_gc_close(self.h)
+
     def udp_close(self):
         self.l.vph_udp_close(self.h)
 
