@@ -6,76 +6,176 @@ batch of `--batch` synthetic 2048x1536 RGGB frames already resident in HBM.  val
 Ranks shard independent camera feeds (no data-path collective); with N > 1 the per-step detection records are
 all-gathered over RCCL (the only exchange the path has).
 
+`python bench.py --gpus N` with no RANK in the environment starts its N rank processes itself (fresh children, spawned
+before this process has touched a GPU or imported torch) and relays rank 0's JSON line; under torchrun (RANK set) it is one rank.
+
 Extra objects on the JSON line:
   roofline     -- the gradientDot+SAT pass: algorithmic 8 B/px (read flat once, write SAT once) x pixels per launch
                   / mean stage duration from hipEvents recorded on the launch stream during the timed region.
-  cpu_baseline -- the CPU oracle (plain-C port, all host cores) timed on a bounded sample of the same workload (rank 0, N=1).
+  cpu_baseline -- the CPU checkers timed on a bounded sample of the same workload (rank 0, N=1); see cpu_baseline().
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from _vp_pkg import load  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def _cgroup_cpu_quota():
+    """Smallest CPU quota (in CPUs) along this process's cgroup path, v2 (cpu.max) or v1 (cfs quota / period); None if unlimited."""
+    best = None
+    try:
+        lines = open("/proc/self/cgroup").read().strip().splitlines()
+    except Exception:
+        lines = []
+    rels = {ln.split(":", 2)[2] for ln in lines if ln.count(":") >= 2} | {"/"}
+    for rel in rels:
+        for base in ("/sys/fs/cgroup", "/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+            p = rel
+            while True:
+                d = os.path.join(base, p.lstrip("/"))
+                try:
+                    txt = open(os.path.join(d, "cpu.max")).read().split()
+                    if txt[0] != "max":
+                        q = int(txt[0]) / int(txt[1])
+                        best = q if best is None else min(best, q)
+                except Exception:
+                    pass
+                try:
+                    q = int(open(os.path.join(d, "cpu.cfs_quota_us")).read())
+                    if q > 0:
+                        q = q / int(open(os.path.join(d, "cpu.cfs_period_us")).read())
+                        best = q if best is None else min(best, q)
+                except Exception:
+                    pass
+                if p in ("", "/"):
+                    break
+                p = os.path.dirname(p)
+    return best
+
+
 def host_cores():
-    """CPU share of this process: cgroup quota if one is set, else the affinity mask, capped at 64 worker threads."""
+    """CPU share of this process from what the kernel says, nothing guessed: min(affinity mask, cgroup CPU quota along the cgroup
+    path).  VP_BENCH_THREADS overrides (recorded in the bench line as `cores`, the threads actually used)."""
+    if os.environ.get("VP_BENCH_THREADS"):
+        return max(1, int(os.environ["VP_BENCH_THREADS"]))
     n = os.cpu_count() or 1
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
-            else:
-                q = int(txt[0])
-                if q > 0:
-                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
-            break
-        except Exception:
-            continue
-    if n > 64:
-        n = 16  # a GPU box exposes every host CPU in the mask but grants one GPU a 16-core share
+    q = _cgroup_cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q + 0.5)))
     return n
 
 
-def opencl_cpu_devices():
-    """report whether a CPU OpenCL device (e.g. PoCL) exists on this box; nothing depends on one."""
+def opencl_devices():
+    """Every OpenCL platform and device of this box with type, CL_DEVICE_IMAGE_SUPPORT and version: whether ANY real OpenCL runtime
+    here could run the reference's unmodified image kernels (resampling.cl:50 needs images + samplers; setup.sh:27-29 makes PoCL the
+    reference's CPU runtime).  Pure enumeration through the ICD loader; run in a child process before any HIP call (bench line)."""
     import ctypes as C
     try:
         cl = C.CDLL("libOpenCL.so.1")
     except OSError:
-        return "no OpenCL ICD loader on this box"
+        return {"loader": None, "platforms": [], "summary": "no OpenCL ICD loader on this box"}
     n = C.c_uint(0)
     if cl.clGetPlatformIDs(0, None, C.byref(n)) != 0 or n.value == 0:
-        return "OpenCL loader present, 0 platforms"
+        return {"loader": "libOpenCL.so.1", "platforms": [], "summary": "OpenCL loader present, 0 platforms"}
     plats = (C.c_void_p * n.value)()
     cl.clGetPlatformIDs(n, plats, None)
-    cpus = 0
+
+    def pinfo(p, what):
+        buf = C.create_string_buffer(512)
+        return buf.value.decode(errors="replace") if cl.clGetPlatformInfo(C.c_void_p(p), C.c_uint(what), C.c_size_t(512), buf, None) == 0 else None
+
+    def dstr(d, what):
+        buf = C.create_string_buffer(512)
+        return buf.value.decode(errors="replace") if cl.clGetDeviceInfo(C.c_void_p(d), C.c_uint(what), C.c_size_t(512), buf, None) == 0 else None
+
+    types = {1: "DEFAULT", 2: "CPU", 4: "GPU", 8: "ACCELERATOR", 16: "CUSTOM"}
+    out, n_cpu, n_img = [], 0, 0
     for p in plats:
+        entry = {"name": pinfo(p, 0x0902), "version": pinfo(p, 0x0901), "devices": []}
         m = C.c_uint(0)
-        if cl.clGetDeviceIDs(C.c_void_p(p), C.c_ulong(2), 0, None, C.byref(m)) == 0:  # CL_DEVICE_TYPE_CPU
-            cpus += m.value
-    return f"{n.value} OpenCL platform(s), {cpus} CPU device(s)" + ("" if cpus else ": the reference's own OpenCL path cannot run here")
+        rc = cl.clGetDeviceIDs(C.c_void_p(p), C.c_ulong(0xFFFFFFFF), 0, None, C.byref(m))
+        if rc == 0 and m.value:
+            devs = (C.c_void_p * m.value)()
+            cl.clGetDeviceIDs(C.c_void_p(p), C.c_ulong(0xFFFFFFFF), m, devs, None)
+            for d in devs:
+                t = C.c_ulong(0)
+                cl.clGetDeviceInfo(C.c_void_p(d), C.c_uint(0x1000), C.c_size_t(8), C.byref(t), None)
+                img = C.c_uint(0)
+                cl.clGetDeviceInfo(C.c_void_p(d), C.c_uint(0x1016), C.c_size_t(4), C.byref(img), None)
+                tn = "|".join(v for k, v in types.items() if t.value & k) or hex(t.value)
+                entry["devices"].append({"name": dstr(d, 0x102B), "type": tn, "image_support": bool(img.value), "device_version": dstr(d, 0x102F),
+                                         "opencl_c_version": dstr(d, 0x103D)})
+                n_cpu += bool(t.value & 2)
+                n_img += bool(img.value)
+        else:
+            entry["clGetDeviceIDs"] = rc
+        out.append(entry)
+    ndev = sum(len(e["devices"]) for e in out)
+    summary = f"{len(out)} OpenCL platform(s), {ndev} device(s), {n_cpu} CPU device(s), {n_img} with image support"
+    if n_img == 0:
+        summary += ": no runtime on this box can run the reference's image kernels (resampling.cl:50), so nothing here can pin the oracle"
+    return {"loader": "libOpenCL.so.1", "platforms": out, "summary": summary}
 
 
-def cpu_baseline(cfg, seconds):
-    """The oracle is used here only as the timed CPU baseline, never as part of the measured GPU path: the reference's own kernels
-    compiled for the host (kind 'reference') when oracle/_ref is present, this repo's plain-C port (kind 'port') beside it."""
+def opencl_devices_child():
+    """opencl_devices() in a child process: the AMD OpenCL runtime brings its own ROCr instance, which must not meet PyTorch's HIP runtime."""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--opencl-probe"], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"summary": f"OpenCL probe failed: {e!r}"}
+
+
+def kernels_hash():
+    """Identity of the kernel sources a traffic figure was measured on (profiles/hbm_traffic.json carries the same hash)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vision-processor_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not imported torch nor touched a
+    GPU), relay rank 0's stdout, wait for all, exit with the worst return code."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    for line in out0.splitlines():  # exactly the JSON line goes to stdout; library chatter (e.g. gloo's connection notes) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def cpu_baseline(cfg, seconds, opencl):
+    """The CPU checkers timed on the host cores, never part of the measured GPU path.  kind "reference" (when oracle/_ref is present) =
+    the reference's kernel/*.cl compiled unmodified for x86, linked against oracle/ref_shim.c -- this repo's stand-in for the OpenCL
+    builtin library (work-item ids, image reads / writes, samplers), since no OpenCL runtime that could run them exists here (see
+    `opencl`).  The kernel arithmetic is the reference's compiled code, the image semantics are this repo's reading of the spec.
+    Nested `port` = this repo's plain-C restatement (oracle/vp_oracle.c) on the same cores."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     cores = host_cores()
@@ -95,11 +195,8 @@ def cpu_baseline(cfg, seconds):
         one(n)
         n += 1
     dt = time.perf_counter() - t0
-    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "opencl_cpu_runtime": opencl_cpu_devices(),
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "opencl_runtimes": opencl.get("summary"),
            "sample": f"{n} frames of {cfg.name} through oracle/vp_oracle.c vpo_frame (fp32 sequential SAT, rows sharded over {cores} pthreads), {dt:.1f} s"}
-    # The reference's own kernel/*.cl compiled for x86 (oracle/_ref, prebuilt in the build container and carried along), every NDRange
-    # spread over the host cores in row bands -- how a CPU OpenCL runtime such as PoCL, which is not installed, would run them.  When
-    # that library is present it IS the baseline (kind "reference"); the port's figure stays beside it.
     if O.Ref.available():
         ref = O.Ref()
         ref_scratch = (np.zeros(4 * cfg.qw * cfg.qh, np.uint8), np.zeros(4 * cfg.fw * cfg.fh, np.uint8), np.zeros(cfg.n_flat, np.float32), np.zeros(cfg.n_flat, np.float32),
@@ -119,9 +216,10 @@ def cpu_baseline(cfg, seconds):
         ref_one(0, 1)
         single = 1.0 / (time.perf_counter() - t1)
         port_out = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
-        out = {"value": round(rn / rdt, 3), "unit": "frames/s", "cores": cores, "kind": "reference", "opencl_cpu_runtime": out["opencl_cpu_runtime"],
-               "sample": f"{rn} frames of {cfg.name} through the reference's own kernel/*.cl compiled for x86 (oracle/_ref), each NDRange in row bands over {cores} host threads, "
-                         f"{rdt:.1f} s; one thread: {single:.3f} frames/s", "port": port_out}
+        out = {"value": round(rn / rdt, 3), "unit": "frames/s", "cores": cores, "kind": "reference", "opencl_runtimes": out["opencl_runtimes"],
+               "sample": f"{rn} frames of {cfg.name} through the reference's kernel/*.cl compiled unmodified for x86 (oracle/_ref) and linked against oracle/ref_shim.c, "
+                         f"this repo's stand-in for the OpenCL builtin library (NOT a real OpenCL runtime: none that can run image kernels exists on this box); "
+                         f"each NDRange in row bands over {cores} host threads, {rdt:.1f} s; one thread: {single:.3f} frames/s", "port": port_out}
     return out
 
 
@@ -140,12 +238,23 @@ def main():
                     "slot, host threads, overlapped with the next step's kernels) and gather the encoded SSL_WrapperPackets instead of the blob records. Off by default: "
                     "the headline metric is the GPU hot path.")
     ap.add_argument("--detect-threads", type=int, default=0, help="host threads of the CPU stage (0 = this rank's share of the cores)")
+    ap.add_argument("--opencl-probe", action="store_true", help="print the OpenCL platform / device report as JSON and exit (used as a child process)")
     args = ap.parse_args()
+    if args.opencl_probe:
+        print(json.dumps(opencl_devices()))
+        return 0
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])  # nothing GPU-related has been imported or called in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    # the OpenCL report comes from a child process started before this one touches the GPU
+    opencl = opencl_devices_child() if rank == 0 and world == 1 and not args.no_cpu_baseline else {}
+    import numpy as np
+    import torch
+    from _vp_pkg import load
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no fallback"
     # VP_BENCH_REHEARSE=1 (tools only): every rank on cuda:0 with the gloo backend, to rehearse the N > 1 code path on a one-GPU box
     rehearse = os.environ.get("VP_BENCH_REHEARSE") == "1"
@@ -262,6 +371,10 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
+    ctx.sync()  # raises VP_ERR_TIMEOUT if a bounded look-back wait of the single-pass SAT expired
+    # every step runs the same frames: what the timed steps produce must equal what the warm-up produced
+    warm_cnt = (det["c"][(step_no[0] - 1) & 1] if det is not None and step_no[0] else counter).cpu().numpy().copy()
+    warm_sat = sat[B - 1, cfg.fh - 1, cfg.fw - 1].item() if args.warmup else None
     ctx.events_clear()
     ctx.events_enable(True)
     if dist:
@@ -277,6 +390,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ctx.events_enable(False)
+    ctx.sync()  # a SAT look-back timeout inside the timed region invalidates the run: fail instead of printing a number
+    cnt_now = (det["c"][(step_no[0] - 1) & 1] if det is not None else counter).cpu().numpy()
+    if args.warmup:
+        assert np.array_equal(cnt_now, warm_cnt), "the timed steps' blob counters differ from the warm-up's on identical input"
+        assert sat[B - 1, cfg.fh - 1, cfg.fw - 1].item() == warm_sat, "the timed steps' SAT differs from the warm-up's on identical input"
+    assert int(cnt_now[:, 0].min()) >= cfg.n_robots * 5, f"fewer blobs than rendered robot discs: {cnt_now[:, 0].min()}"
     stage_ms = {}
     for name, ms in ctx.event_times():
         stage_ms.setdefault(name, []).append(ms)
@@ -285,17 +404,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    coll = "gloo (one-GPU rehearsal)" if rehearse else "RCCL"
     if rank == 0:
-        cnt = (det["c"][(step_no[0] - 1) & 1] if det is not None else counter).cpu().numpy()
+        cnt = cnt_now
         sat_ms = float(np.mean(stage_ms["gradientDot+sat"]))
         algo_bytes = 8.0 * cfg.n_flat * B
         achieved = algo_bytes / (sat_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes of this same command (tools/profile_round.sh -> profiles/hbm_traffic.json), valid only
+        # for the kernel sources it was measured on: the entry carries their hash, a mismatch gives null
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            key = f"{args.workload}/b{B}/{args.sat}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tpath)).get(f"{args.workload}/b{B}/{args.sat}", {})
+            if ent.get("kernels_hash") == kernels_hash():
+                traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
         out = {
             "metric": "frames/s at 2048x1536 (whole hot path raw2quad->blobList, inputs resident in HBM)",
             "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -303,8 +425,8 @@ def main():
             "dtype": "u8/int32 (fp32 for coordinates and scores)", "data": "synthetic",
             "config": {"workload": cfg.name, "frames_per_step_per_gpu": B, "sensor": "2048x1536 RGGB8", "flat": f"{cfg.fw}x{cfg.fh}", "grad_offset": cfg.grad_offset,
                        "circle_radius": cfg.circle_radius, "list_radius": cfg.list_radius, "max_blobs": mm, "sat_variant": args.sat, "list_order": args.order,
-                       "sampler": "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (", RCCL all-gather of detection records per step" if dist else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                       "sampler": "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (f", {coll} all-gather of detection records per step" if dist else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "gradientDot+SAT pass", "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},
             "stage_ms_per_step": {k: round(float(np.mean(v)), 4) for k, v in stage_ms.items()},
             "blobs_per_frame": float(np.minimum(cnt[:, 0], mm).mean()),
@@ -329,15 +451,17 @@ def main():
                 allp = feeds.unpack_packets(det["gath"][last])
                 out["detect"]["gathered_packets"] = sum(1 for r in allp for p in r if p)
                 assert allp[0] == mine
-            out["config"]["sharding"] = f"{world} x {B} independent feeds" + (", RCCL all-gather of SSL_WrapperPackets per step" if dist else "")
+            out["config"]["sharding"] = f"{world} x {B} independent feeds" + (f", {coll} all-gather of SSL_WrapperPackets per step" if dist else "")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, opencl)
+            out["opencl"] = opencl
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -19,12 +19,12 @@
 // aligned 8-byte {tag, value} word per element, written by ONE agent-scope relaxed store (global_store_dwordx2 sc1) and
 // polled by agent-scope relaxed loads (global_load_dwordx2 sc1): the data is the flag, no fence, no L1 staleness.
 // tag = (epoch << 2) | state (1 aggregate, 2 inclusive); `epoch` is bumped per launch so stale granules never match.
-// Forward progress does not depend on dispatch order: tiles are claimed in raster order from a ticket counter, so a
-// workgroup only ever waits on tiles whose workgroups have already started.  Every spin is bounded; on expiry the kernel
-// raises a device abort word and a pinned host flag, finishes with garbage and the host reports VP_ERR_TIMEOUT.
+// Forward progress does not depend on dispatch order: tiles are claimed from a ticket counter in an order that is a linear
+// extension of the carry dependencies (anti-diagonals), so a workgroup only ever waits on tiles whose workgroups have started.
+// Every spin is bounded; on expiry the kernel raises a device abort word and a pinned host flag, finishes with garbage and the
+// host reports VP_ERR_TIMEOUT.
 #include "vp_common.h"
 
-#include <cstdlib>
 #include <vector>
 
 typedef unsigned long long u64;
@@ -41,14 +41,13 @@ constexpr uint32_t ST_AGG = 1, ST_INC = 2;
 struct TiledArgs {
 	int w, h, o;
 	int tilesX, tilesY, nTiles, batch;
-	int pitch, off; // LDS raw-tile row pitch (dwords) and column of the tile interior
+	int pitch;      // generic kernel: size of the LDS halo array in dwords
 	uint32_t ticket_base, epoch;
 	u64 *V, *H, *K; // carry granules: [tile][TW], [tile][TH], [tile]
 	const uint32_t* order; // ticket -> (ti << 16 | tj): anti-diagonal order of the tile grid (a linear extension of the carry dependencies)
 	uint32_t* ctrl; // [0] abort word, [16 + 16 f] ticket counter of frame f (monotonic across launches, one 64-B line each)
 	int* host_flag; // pinned, device-mapped
 	VpStrips strips; // optional halo strips (base == nullptr: halo columns are read from flat)
-	int debug;      // timing experiments only (VP_SAT_DEBUG env): bit0 = skip look-back waits (WRONG results)
 	int single;     // k_sat_fast2: as many workgroups as tiles per frame -- each takes ONE ticket and none in advance
 };
 
@@ -57,13 +56,6 @@ __device__ __forceinline__ u64 ld_granule(const u64* p) {
 }
 __device__ __forceinline__ void st_granule(u64* p, uint32_t epoch, uint32_t state, int value) {
 	__hip_atomic_store((gu64*)p, ((u64)((epoch << 2) | state) << 32) | (uint32_t)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// streaming (non-temporal) 16-byte load: the flat tile is read once by this kernel
-__device__ __forceinline__ uint4 nt_load_u4(const uint32_t* p) {
-	typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
-	const v4u_ v = __builtin_nontemporal_load(reinterpret_cast<const v4u_*>(p));
-	return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // inclusive wave-64 prefix sum in 6 DPP adds (row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31)
@@ -106,17 +98,12 @@ __device__ __forceinline__ bool aborted(const TiledArgs& a) {
 // Exclusive carry of this lane's element along one chain: walk the predecessors (nearest first), adding aggregates
 // until an inclusive granule is met.  `g` points at THIS tile's granule for this lane, predecessors are `stride`
 // granules apart.  Wave-uniform control flow; returns false on timeout / abort.
-template<bool DBG = true>
 __device__ __forceinline__ bool lookback(const u64* g, long stride, int npred, const TiledArgs& a, int& carry, bool active = true) {
 	constexpr int WIN = 4; // predecessor granules kept in flight per round
 	int acc = 0;
 	bool done = !active; // lanes beyond the vector length ride along
 	carry = 0;
-	if(DBG && (a.debug & 1)) return true;
-	unsigned n_win = 0, n_repoll = 0;
-	const bool stats = DBG && (a.debug & 4) && (threadIdx.x & 63) == 0;
 	for(int k0 = 1; k0 <= npred; k0 += WIN) {
-		n_win++;
 		u64 v[WIN];
 #pragma unroll
 		for(int q = 0; q < WIN; q++) v[q] = (k0 + q <= npred) ? ld_granule(g - (long)(k0 + q) * stride) : 0;
@@ -132,7 +119,6 @@ __device__ __forceinline__ bool lookback(const u64* g, long stride, int npred, c
 					return false;
 				}
 				__builtin_amdgcn_s_sleep(1);
-				n_repoll++;
 				v[q] = ld_granule(g - (long)(k0 + q) * stride);
 				tag = (uint32_t)(v[q] >> 32);
 			}
@@ -142,7 +128,6 @@ __device__ __forceinline__ bool lookback(const u64* g, long stride, int npred, c
 			}
 			if(__all(done)) {
 				carry = acc;
-				if(stats) { atomicAdd(a.ctrl + 8, n_win); atomicAdd(a.ctrl + 9, n_repoll); atomicAdd(a.ctrl + 10, 1u); atomicAdd(a.ctrl + 11, (unsigned)(k0 + q)); }
 				return true;
 			}
 		}
@@ -151,22 +136,12 @@ __device__ __forceinline__ bool lookback(const u64* g, long stride, int npred, c
 	return true;
 }
 
-// Workgroup barrier that orders LDS only.  __syncthreads() would also drain the loader's in-flight LDS-DMA (vmcnt(0)).
+// Workgroup barrier that orders LDS only (no vmcnt drain).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
-
-// MODE 0: input is a float gradDot image (vp_sat).  MODE -1: fused gradDot, synchronous tile loads (any offset, any
-// width).  MODE 1: fused gradDot with the loader wavefront (wave 3) streaming the NEXT tile into LDS by LDS-DMA
-// (global_load_lds, no VGPRs) while waves 0-2 look back for the current one; needs w % 4 == 0 and a 16-byte aligned flat.
-// Tickets are requested by the loader's lane 0 one tile ahead: neither the atomic nor the loads sit on the critical path.
-//
-// LDS image of a tile: interior I[rows][64] dwords (rows = TH + 2o, one 256-B row per 16 lanes => a wave instruction of
-// 16 B per lane lands 4 rows contiguously, which is what LDS-DMA requires) followed by the halo columns Hh[rows][2o].
-// Same walk, but the two nearest predecessors were polled EARLY (pre0 = 1 back, pre1 = 2 back, loaded at the top of the
-// tile, before its own sums exist): with the anti-diagonal order they are nearly always inclusive by now, so the carry
-// resolves without a memory round trip on the critical path.  `resolved` tells the caller it may skip the aggregate state.
+// The two nearest predecessors of a chain were polled EARLY (pre0 = 1 back, pre1 = 2 back, loaded at the top of the tile, before
+// its own sums exist): with the anti-diagonal order they are nearly always inclusive by now, so the carry resolves without a
+// memory round trip on the critical path.  A true return tells the caller it may skip the aggregate state.
 __device__ __forceinline__ bool early_resolve(u64 pre0, u64 pre1, int npred, const TiledArgs& a, int& carry) {
 	const uint32_t t0 = (uint32_t)(pre0 >> 32), t1 = (uint32_t)(pre1 >> 32);
 	const bool r0 = (t0 >> 2) == a.epoch && (t0 & 3u) != 0;
@@ -176,16 +151,17 @@ __device__ __forceinline__ bool early_resolve(u64 pre0, u64 pre1, int npred, con
 	return __all(inc0 || (r0 && inc1));
 }
 
-template<int MODE>
+// Generic kernel: any gradient offset, any width.  FUSED = false: the input is a float gradDot image (vp_sat); FUSED = true: the
+// gradient dot product is formed from the flat tile.  Plain synchronous tile loads: the shapes real geometries produce (offset
+// 1..4) run k_sat_fast2 below; this is the fallback for offset 0 / > 4 and for the unfused entry point.
+// LDS image of a tile: interior I[rows][64] dwords (rows = TH + 2o) followed by the halo columns Hh[rows][2o].
+template<bool FUSED>
 __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
-	constexpr bool FUSED = MODE != 0;
-	constexpr bool PIPE = MODE > 0;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int o = FUSED ? a.o : 0;
 	const int rows = TH + 2 * o;
 	uint32_t* I = reinterpret_cast<uint32_t*>(smem);
-	const int rowsPad = (rows + 3) & ~3; // DMA pieces are 4 rows: the last one may spill into the slack rows
-	uint32_t* Hh = I + rowsPad * TW;
+	uint32_t* Hh = I + rows * TW;
 	int* S = reinterpret_cast<int*>(Hh + a.pitch); // a.pitch = halo array size in dwords, padded to a multiple of 4
 	int* T = S + TH * TW;
 	int* Av = T + NWAVES * TW;
@@ -194,8 +170,8 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int w = a.w, h = a.h;
-	// One ticket queue per frame: workgroup b serves frame b % batch; tiles of a frame are claimed in raster order and a
-	// workgroup works through its tickets in increasing order.  (A single counter would serialise the grid at ~88 atomics/us.)
+	// One ticket queue per frame: workgroup b serves frame b % batch; a workgroup works through its tickets in increasing order.
+	// (A single counter would serialise the grid at ~88 atomics/us.)
 	const int perFrame = a.tilesX * a.tilesY;
 	const int f = (int)(blockIdx.x % (unsigned)a.batch);
 	uint32_t* queue = a.ctrl + 16 + 16 * f;
@@ -205,7 +181,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 	int32_t* out = sat + frame;
 	const bool loader = tid == 3 * 64; // lane 0 of wave 3 owns the ticket queue
 
-	uint32_t pending = 0; // loader: ticket requested one tile ahead
+	uint32_t pending = 0; // ticket requested one tile ahead
 	if(loader) {
 		const uint32_t t0 = atomicAdd(queue, 1u);
 		pending = atomicAdd(queue, 1u);
@@ -215,46 +191,13 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 	int rem = misc[0];
 	if(rem < 0 || rem >= perFrame) return; // two tickets taken, none valid: the host accounts for exactly two overshoots
 
-	// LDS-DMA of one full-width tile by one wavefront: ceil(rows/4) 1-KiB pieces + the halo columns, 64 dwords apiece
-	auto dma_tile = [&](int x0, int y0) {
-		const int c4 = lane & 15, r0 = lane >> 4;
-		for(int p = 0; p < rows; p += 4) {
-			const int r = min(p + r0, rows - 1); // the last piece may run past the tile: re-fetch the last row into the slack
-			const uint32_t* g = flat + (size_t)vp_clampi(y0 - o + r, 0, h - 1) * w + x0 + 4 * c4;
-			__builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(I + p * TW), 16, 0, 0);
-		}
-		const int nh = rows * 2 * o;
-		for(int e0 = 0; e0 < nh; e0 += 64) {
-			const int e = min(e0 + lane, nh - 1);
-			const int r = e / (2 * o), k = e - r * (2 * o);
-			const int gx = k < o ? x0 - o + k : x0 + TW + (k - o);
-			const uint32_t* g = flat + (size_t)vp_clampi(y0 - o + r, 0, h - 1) * w + vp_clampi(gx, 0, w - 1);
-			__builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(Hh + e0), 4, 0, 0);
-		}
-	};
-	bool staged = false; // wave 3: the current tile was (or is being) delivered by LDS-DMA
-	if(PIPE && wv == 3) {
-		const uint32_t t0 = a.order[rem];
-		const int tj0 = (int)(t0 & 0xFFFF), ti0 = (int)(t0 >> 16);
-		if(tj0 * TW + TW <= w) {
-			dma_tile(tj0 * TW, ti0 * TH);
-			staged = true;
-		}
-	}
-
-	unsigned long long ph[5] = {0, 0, 0, 0, 0};
-	const bool stamp = (a.debug & 8) && lane == 0 && (wv == 0 || wv == 3);
 	for(;;) {
-		const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		const uint32_t tcur = a.order[rem];
 		const int ti = (int)(tcur >> 16), tj = (int)(tcur & 0xFFFF);
 		const int x0 = tj * TW, y0 = ti * TH;
-		const bool full = x0 + TW <= w; // full-width tile: DMA path
 
 		// ---- A: the tile (+ halo) in LDS; publish the next ticket, request the one after --------------------------------
-		if(PIPE && full) {
-			// delivered by the loader's LDS-DMA; the __syncthreads() below drains it (vmcnt(0)) before anyone reads
-		} else if(FUSED) {
+		if(FUSED) {
 			for(int r = wv; r < rows; r += NWAVES) {
 				const int gy = vp_clampi(y0 - o + r, 0, h - 1);
 				I[r * TW + lane] = flat[(size_t)gy * w + vp_clampi(x0 + lane, 0, w - 1)];
@@ -271,8 +214,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 		}
 		if(loader) misc[3] = (int)(pending - a.ticket_base); // requested a whole tile ago: long since returned
 		__syncthreads();
-		const unsigned long long ts1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		if(loader) pending = atomicAdd(queue, 1u); // after the draining barrier, so nobody waits for it
+		if(loader) pending = atomicAdd(queue, 1u);
 		const int next = misc[3];
 		const bool more = next >= 0 && next < perFrame;
 
@@ -282,8 +224,8 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			const bool xin = x0 + lane < w;
 			// horizontal taps cross into the halo array at the tile's edge columns
 			const int xp = lane + o, xn = lane - o;
-			const int offp = xp < TW ? xp : rowsPad * TW + o + (xp - TW), strp = xp < TW ? TW : 2 * o;
-			const int offn = xn >= 0 ? xn : rowsPad * TW + o + xn, strn = xn >= 0 ? TW : 2 * o;
+			const int offp = xp < TW ? xp : rows * TW + o + (xp - TW), strp = xp < TW ? TW : 2 * o;
+			const int offn = xn >= 0 ? xn : rows * TW + o + xn, strn = xn >= 0 ? TW : 2 * o;
 #pragma unroll 4
 			for(int rr = 0; rr < SEG; rr++) {
 				const int r = wv * SEG + rr;
@@ -302,9 +244,8 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			T[wv * TW + lane] = run;
 		}
 		lds_barrier();
-		const unsigned long long ts2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
-		// ---- C/D: aggregates, publication, look-back (waves 0-2); wave 3 streams the next tile into LDS meanwhile ------
+		// ---- C/D: aggregates, publication, look-back (waves 0-2) ----------------------------------------------------------
 		const size_t tile = (size_t)f * perFrame + (size_t)ti * a.tilesX + tj; // granules are indexed by grid position
 		if(wv == 0) { // column chain: A(x)
 			const int pc = T[lane] + T[TW + lane] + T[2 * TW + lane] + T[3 * TW + lane]; // bottom row of the local SAT
@@ -321,7 +262,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			const int y = act ? lane : TH - 1;
 			int pr = S[y * TW + TW - 1]; // right column of the local SAT
 			const int seg = y / SEG;
-			for(int s = 0; s < seg; s++) pr += T[s * TW + TW - 1];
+			for(int sg = 0; sg < seg; sg++) pr += T[sg * TW + TW - 1];
 			u64* g = a.H + tile * TH + y;
 			int carry = 0;
 			if(tj > 0) {
@@ -340,20 +281,8 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			int carry = 0;
 			if(ti > 0) lookback(a.K + tile, a.tilesX, ti, a, carry);
 			if(lane == 0) misc[1] = carry;
-		} else if(PIPE) { // wave 3: the loader.  I / Hh were last read in phase B, before the barrier above.
-			staged = false;
-			if(more) {
-				const uint32_t tn = a.order[next];
-				const int ntj = (int)(tn & 0xFFFF), nti = (int)(tn >> 16);
-				if(ntj * TW + TW <= w) {
-					dma_tile(ntj * TW, nti * TH);
-					staged = true;
-				}
-			}
 		}
-		const unsigned long long ts3a = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		lds_barrier();
-		const unsigned long long ts3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 		const int K = misc[1];
 		if(wv == 1 && lane == 0 && ti > 0) st_granule(a.K + tile, a.epoch, ST_INC, K + misc[2]);
 
@@ -368,7 +297,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			for(int q = 0; q < TH / 16; q++) {
 				const int r = q * 16 + rr, gy = y0 + r;
 				const int seg = r / SEG;
-				int4 add = base; // + totals of the 16-row... SEG-row segments above this row's segment
+				int4 add = base; // + totals of the SEG-row segments above this row's segment
 #pragma unroll
 				for(int sgm = 0; sgm < NWAVES - 1; sgm++) {
 					if(sgm < seg) {
@@ -376,9 +305,9 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 						add = make_int4(add.x + t.x, add.y + t.y, add.z + t.z, add.w + t.w);
 					}
 				}
-				const int4 s = *reinterpret_cast<const int4*>(S + r * TW + 4 * cg);
+				const int4 sv = *reinterpret_cast<const int4*>(S + r * TW + 4 * cg);
 				const int b = Bv[r];
-				const int4 v = make_int4(s.x + add.x + b, s.y + add.y + b, s.z + add.z + b, s.w + add.w + b);
+				const int4 v = make_int4(sv.x + add.x + b, sv.y + add.y + b, sv.z + add.z + b, sv.w + add.w + b);
 				if(gy < h) {
 					if(vec) *reinterpret_cast<int4*>(out + (size_t)gy * w + gx) = v;
 					else {
@@ -390,322 +319,26 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 				}
 			}
 		}
-		if(stamp) {
-			const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
-			ph[0] += ts1 - ts0; ph[1] += ts2 - ts1; ph[2] += ts3a - ts2; ph[3] += ts3 - ts3a; ph[4] += ts4 - ts3;
-		}
 		if(!more) break;
 		rem = next;
 		lds_barrier(); // S/T/Av/Bv/misc of this tile are dead only now
 	}
-	(void)staged;
-	if(stamp) {
-		unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.ctrl + 16 + 16 * a.batch) + (wv == 3 ? 8 : 0);
-		for(int k = 0; k < 5; k++) atomicAdd(acc + k, ph[k]);
-	}
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fast path (compile-time gradient offset O in 1..4, w % 64 == 0, 16-byte aligned images): the kernel the benchmark runs.
-//
-// Differences from the generic kernel above, each one answering a measurement (in-kernel s_memtime stamps, 64x64 tiles,
-// 4 workgroups per CU): phase B cost 8.3k cycles per tile and the loader's LDS-DMA issue 7.1k (~320 cycles per 1-KiB piece).
+// Fast path (compile-time gradient offset O in 1..4): the kernel the benchmark runs.  Each design point answers a measurement
+// (DESIGN.md section 4 has the history):
 //   * phase B works on 4 pixels per lane: a 16-lane DPP row holds one 64-pixel tile row, a wavefront sweeps 4 row blocks at
 //     once, taps come from ds_read_b128, the row scan is 3 serial adds + 4 DPP steps, column sums stay in registers;
-//   * the next tile is prefetched into registers by all 256 threads (5 x 16 B + <= 3 halo dwords each) right before the
-//     look-back polls are issued, and written to LDS at the top of the next iteration;
-//   * sub-segment totals T16 alias the (dead) raw tile, so LDS stays <= 37.3 KB per workgroup (4 workgroups per CU).
+//   * the sub-segment-local SAT plane lives in registers: phase E uses phase B's pixel-to-lane mapping, so the 16 values a lane
+//     produced are the 16 values it completes and stores (24.6 KB of LDS per workgroup: 5 or 6 workgroups per CU);
+//   * the next tile is prefetched into registers by all 256 threads (5 x 16 B + <= 2 x 2 halo dwords each) behind the look-back
+//     and written to LDS at the top of the next iteration; its addresses are 32-bit lane offsets against buffer descriptors with
+//     a scalar tile offset (no 64-bit VGPR arithmetic, no divisions in the loop);
+//   * wave 3, which has no carry chain, turns the sub-segment totals into their exclusive prefix while waves 0-2 look back.
 // LDS image of a tile: raw[rows][72] dwords = [4 - O pad | O halo | 64 interior | O halo | pad], rows = 64 + 2 O.
-// DBG: carries the phase stamps / ablation switches of VP_SAT_DEBUG; the shipped instantiation (DBG = false) has none of them
-// (they cost registers: with the 128-VGPR budget of 4 waves per SIMD any spill puts scratch traffic on the same vmcnt queue as
-// the tile prefetch and drains it).
-template<int O, bool DBG>
-__global__ __launch_bounds__(256, 4) void k_sat_fast(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
-	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
-	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
-	constexpr int NI = (ROWS + 15) / 16;           // interior: 16 lanes x 16 B per row, 16 rows per pass
-	constexpr int NHAL = (ROWS * 2 * O + 255) / 256; // halo dwords per thread
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	// O <= 2: raw 19.6 KB + S 16 KB + T16 4 KB + carries = 40 608 B <= 160 KB / 4, so T16 gets storage of its own and two of the
-	// five barriers per tile disappear; O = 3, 4: T16 aliases the raw tile (dead after phase B) behind an extra barrier.
-	constexpr bool ALIAS = O > 2;
-	uint32_t* raw = reinterpret_cast<uint32_t*>(smem);
-	int* S = reinterpret_cast<int*>(raw + ROWS * PITCH);
-	int* Av = S + TH * TW;
-	int* Bv = Av + TW;
-	int* misc = Bv + TH; // [0] first ticket, [1] K, [2] Q, [3] next ticket, [4] wave slot
-	int* T16 = ALIAS ? reinterpret_cast<int*>(smem) : misc + 8; // [16][64] column totals of the 4-row sub-segments
-	int* Rc = (ALIAS ? misc + 8 : T16 + 16 * TW);               // [64] right column of the sub-segment-local SAT (for the row chain)
-
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int w = a.w, h = a.h;
-	const int perFrame = a.tilesX * a.tilesY;
-	const int f = (int)(blockIdx.x % (unsigned)a.batch);
-	uint32_t* queue = a.ctrl + 16 + 16 * f;
-	const size_t frame = (size_t)f * w * h;
-	const uint32_t* flat = in + frame;
-	int32_t* out = sat + frame;
-	const bool loader = tid == 3 * 64;
-	const int dbg = DBG ? a.debug : 0;
-	const bool abl_gran = dbg & 64, abl_store = dbg & 128, abl_load = dbg & 256, abl_comp = dbg & 512;
-
-	uint32_t pending = 0;
-	if(loader) {
-		const uint32_t t0 = atomicAdd(queue, 1u);
-		pending = atomicAdd(queue, 1u);
-		misc[0] = (int)(t0 - a.ticket_base);
-		misc[4] = (int)(__builtin_amdgcn_s_getreg(0x1804) & 3u); // HW_ID.wave_id: differs between workgroups sharing a SIMD
-	}
-	__syncthreads();
-	int rem = misc[0];
-	if(rem < 0 || rem >= perFrame) return;
-	if(dbg & 1024) { // experiment: stagger co-resident workgroups so they do not convoy through the same phase together
-		const int slot = misc[4];
-		for(int i = 0; i < slot * (dbg >> 12); i++) __builtin_amdgcn_s_sleep(16);
-	}
-
-	// ---- register image of the next tile -------------------------------------------------------------------------------
-	uint4 pv0, pv1, pv2, pv3, pv4;
-	uint32_t hv0 = 0, hv1 = 0, hv2 = 0;
-	const int c4 = tid & 15, r16 = tid >> 4;
-#define VP_PF_ROW(P) (min(r16 + 16 * (P), ROWS - 1))
-#define VP_PF_LOAD(P, X0, Y0) nt_load_u4(flat + (size_t)vp_clampi((Y0) - O + VP_PF_ROW(P), 0, h - 1) * w + (X0) + 4 * c4)
-#define VP_HALO_E(J) (min(tid + 256 * (J), ROWS * 2 * O - 1))
-#define VP_HALO_GX(J, X0) ((VP_HALO_E(J) % (2 * O)) < O ? (X0) - O + (VP_HALO_E(J) % (2 * O)) : (X0) + TW + (VP_HALO_E(J) % (2 * O)) - O)
-	// halo element J of the tile at (X0, Y0): from the compact strips when they exist and the neighbour tile does (interior
-	// boundary), else straight from flat with clamp-to-edge (image border: the line is the tile's own)
-	const uint32_t* sbase = a.strips.base ? a.strips.base + (size_t)f * a.strips.frame_words : nullptr;
-	auto halo_load = [&](int e, int X0, int Y0) -> uint32_t {
-		const int r = e / (2 * O), k = e % (2 * O);
-		const int gy = vp_clampi(Y0 - O + r, 0, h - 1);
-		const int tjx = X0 >> 6;
-		if(sbase) {
-			if(k < O && tjx > 0) return sbase[a.strips.left(tjx, gy, k)];
-			if(k >= O && tjx + 1 < a.tilesX) return sbase[a.strips.right(tjx + 1, gy, k - O)];
-		}
-		const int gx = k < O ? X0 - O + k : X0 + TW + (k - O);
-		return flat[(size_t)gy * w + vp_clampi(gx, 0, w - 1)];
-	};
-#define VP_HALO_LOAD(J, X0, Y0) halo_load(VP_HALO_E(J), X0, Y0)
-#define VP_PREFETCH(X0, Y0)                            \
-	do {                                                 \
-		pv0 = VP_PF_LOAD(0, X0, Y0);                     \
-		pv1 = VP_PF_LOAD(1, X0, Y0);                     \
-		pv2 = VP_PF_LOAD(2, X0, Y0);                     \
-		pv3 = VP_PF_LOAD(3, X0, Y0);                     \
-		if(NI > 4) pv4 = VP_PF_LOAD(4, X0, Y0);          \
-		if(!(dbg & 2048)) {                              \
-		hv0 = VP_HALO_LOAD(0, X0, Y0);                   \
-		if(NHAL > 1) hv1 = VP_HALO_LOAD(1, X0, Y0);      \
-		if(NHAL > 2) hv2 = VP_HALO_LOAD(2, X0, Y0);      \
-		}                                                \
-	} while(0)
-#define VP_COMMIT_ROW(P, V)                                                                                       \
-	do {                                                                                                            \
-		if(r16 + 16 * (P) < ROWS) *reinterpret_cast<uint4*>(raw + (r16 + 16 * (P)) * PITCH + 4 + 4 * c4) = (V);    \
-	} while(0)
-#define VP_COMMIT_HALO(J, V)                                                                                      \
-	do {                                                                                                            \
-		const int e_ = tid + 256 * (J);                                                                             \
-		if(e_ < ROWS * 2 * O) {                                                                                     \
-			const int k_ = e_ % (2 * O);                                                                            \
-			raw[(e_ / (2 * O)) * PITCH + (k_ < O ? 4 - O + k_ : 4 + TW + (k_ - O))] = (V);                          \
-		}                                                                                                           \
-	} while(0)
-	pv4 = make_uint4(0, 0, 0, 0);
-	{
-		const uint32_t t0 = a.order[__builtin_amdgcn_readfirstlane(rem)]; // scalar load: off the congested vector-memory path
-		VP_PREFETCH((int)(t0 & 0xFFFF) * TW, (int)(t0 >> 16) * TH);
-	}
-
-	unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	const bool stamp = DBG && (a.debug & 8) && lane == 0 && (wv == 0 || wv == 3);
-	for(;;) {
-		const unsigned long long ts0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		const uint32_t tcur = a.order[__builtin_amdgcn_readfirstlane(rem)];
-		const int ti = (int)(tcur >> 16), tj = (int)(tcur & 0xFFFF);
-		const int x0 = tj * TW, y0 = ti * TH;
-
-		// ---- A: registers -> LDS; publish the next ticket, request the one after --------------------------------------
-		VP_COMMIT_ROW(0, pv0);
-		VP_COMMIT_ROW(1, pv1);
-		VP_COMMIT_ROW(2, pv2);
-		VP_COMMIT_ROW(3, pv3);
-		if(NI > 4) VP_COMMIT_ROW(4, pv4);
-		VP_COMMIT_HALO(0, hv0);
-		if(NHAL > 1) VP_COMMIT_HALO(1, hv1);
-		if(NHAL > 2) VP_COMMIT_HALO(2, hv2);
-		if(loader) misc[3] = (int)(pending - a.ticket_base);
-		lds_barrier();
-		const unsigned long long ts1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		if(loader) pending = atomicAdd(queue, 1u);
-		const int next = misc[3];
-		const bool more = next >= 0 && next < perFrame;
-
-		// early polls: the carries of the two nearest predecessors of each chain, requested before our own sums exist
-		const size_t tile = (size_t)f * perFrame + (size_t)ti * a.tilesX + tj;
-		u64 pre0 = 0, pre1 = 0;
-		if(abl_gran) {
-		} else if(wv == 0 && ti > 0) {
-			const u64* g = a.V + tile * TW + lane;
-			pre0 = ld_granule(g - (long)a.tilesX * TW);
-			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX * TW);
-		} else if(wv == 1 && tj > 0) {
-			const u64* g = a.H + tile * TH + lane;
-			pre0 = ld_granule(g - TH);
-			if(tj > 1) pre1 = ld_granule(g - 2 * TH);
-		} else if(wv == 2 && ti > 0) {
-			const u64* g = a.K + tile;
-			pre0 = ld_granule(g - a.tilesX);
-			if(ti > 1) pre1 = ld_granule(g - 2 * (long)a.tilesX);
-		}
-
-		// ---- B: 4 pixels per lane; lane = 16 ql + m: columns 4m..4m+3, rows 16 wv + 4 q + it --------------------------
-		// q = bit-reversed ql: a ds_read_b128 is serviced in four 16-lane groups that each mix lanes of two adjacent 16-lane rows
-		// ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md, LDS); with the 72-dword pitch those two rows must lie a multiple of 8 tile
-		// rows apart (72 * 8 = 0 mod 64 banks) for the group to cover 64 distinct banks.  ql = 0,1,2,3 -> row blocks 0, 8, 4, 12:
-		// all five tap reads are conflict-free (with q = ql every one of them was 2-way conflicted).
-		const int m = lane & 15, ql = lane >> 4, q = ((ql & 1) << 1) | (ql >> 1);
-		int run0 = 0, run1 = 0, run2 = 0, run3 = 0;
-#pragma unroll 1
-		for(int it = 0; it < (abl_comp ? 0 : 4); it++) {
-			const int r = 16 * wv + 4 * q + it;
-			const uint32_t* c = raw + (r + O) * PITCH + 4 + 4 * m;
-			const uint4 L = *reinterpret_cast<const uint4*>(c - 4), C = *reinterpret_cast<const uint4*>(c), R = *reinterpret_cast<const uint4*>(c + 4);
-			const uint4 U = *reinterpret_cast<const uint4*>(c - O * PITCH), D = *reinterpret_cast<const uint4*>(c + O * PITCH);
-			const uint32_t hx[12] = {L.x, L.y, L.z, L.w, C.x, C.y, C.z, C.w, R.x, R.y, R.z, R.w};
-			int g0 = grad_dot_pk(hx[4 + O], hx[4 - O], D.x, U.x);
-			int g1 = grad_dot_pk(hx[5 + O], hx[5 - O], D.y, U.y);
-			int g2 = grad_dot_pk(hx[6 + O], hx[6 - O], D.z, U.z);
-			int g3 = grad_dot_pk(hx[7 + O], hx[7 - O], D.w, U.w);
-			const bool yin = y0 + r < h;
-			if(!yin) g0 = g1 = g2 = g3 = 0;
-			if(gd_out && yin) *reinterpret_cast<float4*>(gd_out + frame + (size_t)(y0 + r) * w + x0 + 4 * m) = make_float4((float)g0, (float)g1, (float)g2, (float)g3);
-			g1 += g0;
-			g2 += g1;
-			g3 += g2;
-			int s = g3; // inclusive scan of the lane totals over the 16 lanes of this row
-			s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);
-			s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);
-			s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);
-			s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);
-			const int ex = s - g3;
-			run0 += g0 + ex;
-			run1 += g1 + ex;
-			run2 += g2 + ex;
-			run3 += g3 + ex;
-			*reinterpret_cast<int4*>(S + r * TW + 4 * m) = make_int4(run0, run1, run2, run3);
-			if(m == 15) Rc[r] = run3; // S[r][63], compact: the row chain reads it without the 32-way bank conflict of a column read
-		}
-		const unsigned long long tsb1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		if(ALIAS) lds_barrier(); // every wave is done with raw before T16 overwrites it
-		const unsigned long long tsb2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		*reinterpret_cast<int4*>(T16 + (4 * wv + q) * TW + 4 * m) = make_int4(run0, run1, run2, run3);
-		const unsigned long long tsb3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		lds_barrier();
-		const unsigned long long ts2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-
-		// ---- C/D: aggregates, publication, look-back -------------------------------------------------------------------
-		if(wv == 0) { // column chain: A(x)
-			int pc = 0;
-#pragma unroll
-			for(int sg = 0; sg < 16; sg++) pc += T16[sg * TW + lane]; // bottom row of the local SAT
-			u64* g = a.V + tile * TW + lane;
-			int carry = 0;
-			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) {
-				st_granule(g, a.epoch, ST_AGG, pc);
-				lookback<DBG>(g, (long)a.tilesX * TW, ti, a, carry);
-			}
-			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pc);
-			Av[lane] = carry;
-		} else if(wv == 1) { // row chain: B(y), then the corner chain's aggregate Q = B(TH-1)
-			// right column of the local SAT = sub-segment-local value + totals of the sub-segments above: an exclusive prefix over
-			// sub-segments, done as one wave scan (4 lanes share a sub-segment) instead of a dependent loop of up to 15 LDS reads
-			const int t = T16[(lane >> 2) * TW + TW - 1];
-			const int pr = Rc[lane] + scan_incl_dpp((lane & 3) == 0 ? t : 0) - t;
-			u64* g = a.H + tile * TH + lane;
-			int carry = 0;
-			if(!abl_gran && tj > 0 && !early_resolve(pre0, pre1, tj, a, carry)) {
-				st_granule(g, a.epoch, ST_AGG, pr);
-				lookback<DBG>(g, TH, tj, a, carry);
-			}
-			if(!abl_gran) st_granule(g, a.epoch, ST_INC, carry + pr);
-			Bv[lane] = carry;
-			if(lane == TH - 1) {
-				misc[2] = carry;
-				if(!abl_gran) st_granule(a.K + tile, a.epoch, ti > 0 ? ST_AGG : ST_INC, carry);
-			}
-		} else if(wv == 2) { // corner chain
-			int carry = 0;
-			if(!abl_gran && ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback<DBG>(a.K + tile, a.tilesX, ti, a, carry);
-			if(lane == 0) misc[1] = carry;
-		}
-		const unsigned long long ts3a = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		lds_barrier();
-		const unsigned long long ts3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-		const int K = misc[1];
-		if(!abl_gran && wv == 1 && lane == 0 && ti > 0) st_granule(a.K + tile, a.epoch, ST_INC, K + misc[2]);
-		// next tile -> registers: in flight across phase E and the loop barrier, consumed at the next phase A
-		if(more && !abl_load) {
-			const uint32_t tn = a.order[__builtin_amdgcn_readfirstlane(next)];
-			VP_PREFETCH((int)(tn & 0xFFFF) * TW, (int)(tn >> 16) * TH);
-		}
-
-		// ---- E: out = local + (sub-segment totals above) + A(x) + B(y) + K ------------------------------------------------
-		{
-			const int cg = tid & 15, rr = tid >> 4;
-			const int4 av = *reinterpret_cast<const int4*>(Av + 4 * cg);
-			int4 add = make_int4(av.x + K, av.y + K, av.z + K, av.w + K);
-			int sgdone = 0; // sub-segments already folded into `add`
-			const int gx = x0 + 4 * cg;
-#pragma unroll
-			for(int k = 0; k < 4; k++) {
-				const int r = rr + 16 * k, gy = y0 + r;
-				const int sgneed = r >> 2;
-				for(; sgdone < sgneed; sgdone++) {
-					const int4 t = *reinterpret_cast<const int4*>(T16 + sgdone * TW + 4 * cg);
-					add = make_int4(add.x + t.x, add.y + t.y, add.z + t.z, add.w + t.w);
-				}
-				const int4 sv = *reinterpret_cast<const int4*>(S + r * TW + 4 * cg);
-				const int b = Bv[r];
-				if(gy < h && !abl_store) { typedef int v4i_ __attribute__((ext_vector_type(4))); const v4i_ o4 = {sv.x + add.x + b, sv.y + add.y + b, sv.z + add.z + b, sv.w + add.w + b}; __builtin_nontemporal_store(o4, reinterpret_cast<v4i_*>(out + (size_t)gy * w + gx)); }
-			}
-		}
-		if(stamp) {
-			const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
-			ph[0] += ts1 - ts0; ph[1] += ts2 - ts1; ph[2] += ts3a - ts2; ph[3] += ts3 - ts3a; ph[4] += ts4 - ts3;
-			ph[5] += tsb1 - ts1; ph[6] += tsb2 - tsb1; ph[7] += tsb3 - tsb2;
-		}
-		if(!more) break;
-		rem = next;
-		// No barrier here unless T16 aliases raw: the next commit only writes raw (last read before the barrier that follows
-		// phase B), and S / T16 / Av / Bv / misc are rewritten only behind the next tile's own barriers.
-		if(ALIAS) lds_barrier();
-	}
-	if(stamp) {
-		unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.ctrl + 16 + 16 * a.batch) + (wv == 3 ? 8 : 0);
-		for(int k = 0; k < 8; k++) atomicAdd(acc + k, ph[k]);
-	}
-#undef VP_PF_ROW
-#undef VP_PF_LOAD
-#undef VP_HALO_E
-#undef VP_HALO_GX
-#undef VP_HALO_LOAD
-#undef VP_PREFETCH
-#undef VP_COMMIT_ROW
-#undef VP_COMMIT_HALO
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Second generation of the fast path.  k_sat_fast is limited by the bytes it keeps in flight: 4 workgroups per CU (LDS 40.8 KB
-// and ~121 VGPRs each) x 20 KB of prefetch, and only between the prefetch and its use.  Here
-//   * the sub-segment-local SAT plane S (16 KB of LDS) lives in registers: phase E uses phase B's pixel-to-lane mapping, so the
-//     16 values a lane produced are the 16 values it completes and stores;
-//   * the prefetch addresses are 32-bit lane offsets against buffer descriptors with a scalar tile offset (no 64-bit VGPR
-//     arithmetic, no divisions in the loop: the register peak of k_sat_fast sat in exactly that code);
-// which brings a workgroup to 24.6 KB of LDS and <= WPC-dependent VGPR budget: WPC = 5 or 6 workgroups per CU.
-// Works for every O in 1..4 (nothing aliases the raw tile).  Same granule protocol, same tile order, same results.
+// RAG: width not a multiple of 64 (the last tile column clamps / masks per pixel).  GD: also write the F32 gradDot view.
 template<int O, int WPC, bool GD, bool RAG>
 __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
 	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
@@ -834,7 +467,10 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 		VP2_PREFETCH((int)(t0 & 0xFFFF) * TW, (int)(t0 >> 16) * TH);
 	}
 
-	// phase B / E mapping: lane = 16 ql + m, columns 4m..4m+3, rows 16 wv + 4 q + it (q = bit-reversed ql: see k_sat_fast)
+	// phase B / E mapping: lane = 16 ql + m, columns 4m..4m+3, rows 16 wv + 4 q + it, q = bit-reversed ql: a ds_read_b128 is serviced in
+	// four 16-lane groups that each mix lanes of two adjacent 16-lane rows ({0-3, 12-15, 20-27}, ... MI355X_MICROARCH.md, LDS); with the
+	// 72-dword pitch those two rows must lie a multiple of 8 tile rows apart (72 * 8 = 0 mod 64 banks) for the group to cover 64
+	// distinct banks.  ql = 0,1,2,3 -> row blocks 0, 8, 4, 12: all five tap reads are conflict-free (with q = ql each was 2-way conflicted).
 	const int m = lane & 15, ql = lane >> 4, q = ((ql & 1) << 1) | (ql >> 1);
 	const int sg_mine = 4 * wv + q;
 	const uint32_t out_voff = ((uint32_t)(16 * wv + 4 * q) * (uint32_t)w + 4u * (uint32_t)m) * 4u;
@@ -929,7 +565,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 		}
 		lds_barrier();
 
-		// ---- C/D: aggregates, publication, look-back (as k_sat_fast) -----------------------------------------------------
+		// ---- C/D: aggregates, publication, look-back --------------------------------------------------------------------------
 		if(wv == 0) {
 			int pc = 0;
 #pragma unroll
@@ -939,7 +575,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 			int carry = 0;
 			if(ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) {
 				st_granule(g, a.epoch, ST_AGG, pc);
-				lookback<false>(g, (long)a.tilesX * TW, ti, a, carry);
+				lookback(g, (long)a.tilesX * TW, ti, a, carry);
 			}
 			st_granule(g, a.epoch, ST_INC, carry + pc);
 			Av[lane] = carry;
@@ -951,7 +587,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 			int carry = 0;
 			if(tj > 0 && !early_resolve(pre0, pre1, tj, a, carry)) {
 				st_granule(g, a.epoch, ST_AGG, pr);
-				lookback<false>(g, TH, tj, a, carry);
+				lookback(g, TH, tj, a, carry);
 			}
 			st_granule(g, a.epoch, ST_INC, carry + pr);
 			Bv[lane] = carry;
@@ -961,7 +597,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 			}
 		} else if(wv == 2) {
 			int carry = 0;
-			if(ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback<false>(a.K + tile, a.tilesX, ti, a, carry);
+			if(ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) lookback(a.K + tile, a.tilesX, ti, a, carry);
 			if(lane == 0) misc[1] = carry;
 		} else { // wave 3 has no chain: it turns the sub-segment totals into their exclusive prefix for phase E
 			int acc = 0;
@@ -1036,12 +672,11 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	a.nTiles = (int)nt;
 	a.batch = batch;
 	const int rawRows = TH + 2 * o;
-	a.off = 0;
-	a.pitch = (rawRows * 2 * o + 63 + 3) & ~3; // halo array (dwords): whole 64-dword DMA pieces, 16-byte multiple
-	const size_t lds = sizeof(int) * ((size_t)((rawRows + 3) & ~3) * TW + a.pitch + TH * TW + NWAVES * TW + TW + TH + 8);
+	a.pitch = (rawRows * 2 * o + 3) & ~3; // halo array (dwords), 16-byte multiple
+	const size_t lds = sizeof(int) * ((size_t)rawRows * TW + a.pitch + TH * TW + NWAVES * TW + TW + TH + 8);
 
-	// persistent carry state (slot 1): [control: abort word + one 64-B ticket line per frame][V][H][K]
-	const size_t bCtl = 64 * ((size_t)batch + 1) + 128; // + debug phase accumulators
+	// persistent carry state (slot 1): [control: abort word + one 64-B ticket line per frame][tile order][V][H][K]
+	const size_t bCtl = 64 * ((size_t)batch + 1);
 	const size_t bOrd = (sizeof(uint32_t) * (size_t)a.tilesX * a.tilesY + 255) & ~size_t(255);
 	const size_t bV = sizeof(u64) * (size_t)a.nTiles * TW, bH = sizeof(u64) * (size_t)a.nTiles * TH, bK = sizeof(u64) * (size_t)a.nTiles;
 	void* base = nullptr;
@@ -1078,61 +713,36 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 		// (re)build the visiting order of this tile grid: anti-diagonal wavefronts.  It is a linear extension of the carry
 		// dependencies, and both the left and the upper neighbour of a tile are claimed about one diagonal length of tickets
 		// earlier, so their carries are usually published by the time a tile looks back (raster / Morton orders leave the
-		// left neighbour one ticket ahead: measured ~3.7 re-polls per chain).  VP_SAT_ORDER=raster|morton for experiments.
+		// left neighbour one ticket ahead: measured ~3.7 re-polls per chain against 0.24).
 		std::vector<uint32_t> ord;
 		ord.reserve((size_t)a.tilesX * a.tilesY);
-		const char* oe = getenv("VP_SAT_ORDER");
-		const int mode = !oe ? 0 : (oe[0] == 'r' ? 1 : (oe[0] == 'm' ? 2 : 0));
-		if(mode == 0) {
-			for(int d = 0; d < a.tilesX + a.tilesY - 1; d++)
-				for(int y = 0; y < a.tilesY; y++) {
-					const int x = d - y;
-					if(x >= 0 && x < a.tilesX) ord.push_back(((uint32_t)y << 16) | (uint32_t)x);
-				}
-		} else if(mode == 1) {
-			for(int y = 0; y < a.tilesY; y++)
-				for(int x = 0; x < a.tilesX; x++) ord.push_back(((uint32_t)y << 16) | (uint32_t)x);
-		} else {
-			int bits = 0;
-			while((1 << bits) < a.tilesX || (1 << bits) < a.tilesY) bits++;
-			for(uint32_t z = 0; z < (1u << (2 * bits)); z++) {
-				uint32_t x = 0, y = 0;
-				for(int b = 0; b < bits; b++) {
-					x |= ((z >> (2 * b)) & 1u) << b;
-					y |= ((z >> (2 * b + 1)) & 1u) << b;
-				}
-				if((int)x < a.tilesX && (int)y < a.tilesY) ord.push_back((y << 16) | x);
+		for(int d = 0; d < a.tilesX + a.tilesY - 1; d++)
+			for(int y = 0; y < a.tilesY; y++) {
+				const int x = d - y;
+				if(x >= 0 && x < a.tilesX) ord.push_back(((uint32_t)y << 16) | (uint32_t)x);
 			}
-		}
 		VP_CHECK_HIP(hipMemcpyAsync(p + bCtl, ord.data(), sizeof(uint32_t) * ord.size(), hipMemcpyHostToDevice, s));
 		VP_CHECK_HIP(hipStreamSynchronize(s)); // ord is a temporary; this path runs only when the shape changes
 	}
 	int* dflag = nullptr;
 	VP_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dflag), ctx->host_flag[stream], 0));
 	a.host_flag = dflag;
-	a.debug = getenv("VP_SAT_DEBUG") ? atoi(getenv("VP_SAT_DEBUG")) : 0;
 	a.strips = vp_make_strips((fused && strips && vp_strips_supported(w, o)) ? const_cast<uint32_t*>(strips) : nullptr, vp_strips_supported(w, o) ? w : 64, h, o >= 1 ? o : 1);
 
 	// persistent grid: P workgroups per frame queue; every workgroup overshoots its queue by exactly two tickets
 	const int perFrame = a.tilesX * a.tilesY;
-	// k_sat_fast2 keeps VP_SAT_WPC (5 or 6) workgroups per CU resident, k_sat_fast 4
-	const int v2_wpc = getenv("VP_SAT_WPC") ? atoi(getenv("VP_SAT_WPC")) : 5;
+	const int wpc = ctx->tune.sat_workgroups_per_cu; // resident workgroups per CU of k_sat_fast2 (vp_ctx_tune; 5 or 6 have their own register budget)
 	// k_sat_fast2 takes any width (the last tile column clamps / masks per pixel); rows need not be 16-byte aligned for buffer accesses
 	const bool aligned16 = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
 			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0);
-	const bool fast_ok = fused && o >= 1 && o <= 4 && ((w % TW) == 0 ? aligned16 : true);
-	const bool v2 = fast_ok && !(getenv("VP_SAT_V2") && atoi(getenv("VP_SAT_V2")) == 0) && !getenv("VP_SAT_DEBUG") && (size_t)w * h * 4 < 0x7fffffffu &&
-			(size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu && (v2_wpc >= 2 && v2_wpc <= 8);
-	int P = ((v2 ? v2_wpc : 4) * ctx->cu_count + batch - 1) / batch;
+	const bool fast = fused && o >= 1 && o <= 4 && ((w % TW) == 0 ? aligned16 : true) && (size_t)w * h * 4 < 0x7fffffffu && (size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu;
+	int P = ((fast ? wpc : 4) * ctx->cu_count + batch - 1) / batch;
 	if(P < 1) P = 1;
 	if(P > perFrame) P = perFrame;
-	a.single = v2 && P >= perFrame ? 1 : 0;
+	a.single = fast && P >= perFrame ? 1 : 0;
 	ctx->sat_ticket_base[stream] += a.single ? (uint32_t)P : (uint32_t)(perFrame + 2 * P);
 	const unsigned grid = (unsigned)P * (unsigned)batch;
-	const bool pipe = fused && o >= 1 && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && !(a.debug & 2);
-	const bool fast = fused && o >= 1 && o <= 4 && (w % TW) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
-			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0) && !(a.debug & 16);
-	if(v2) {
+	if(fast) {
 		const size_t lds2 = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + 32 * TW + TH + TW + TH + 8);
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
 #define VP_FAST2(OO) \
@@ -1141,7 +751,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 				if(graddot_out) k_sat_fast2<OO, 5, true, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 				else k_sat_fast2<OO, 5, false, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 			} else if(graddot_out) k_sat_fast2<OO, 5, true, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
-			else if(v2_wpc == 6) k_sat_fast2<OO, 6, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else if(wpc == 6) k_sat_fast2<OO, 6, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 			else k_sat_fast2<OO, 5, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 		} while(0)
 		if(o == 1) VP_FAST2(1);
@@ -1149,47 +759,11 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 		else if(o == 3) VP_FAST2(3);
 		else VP_FAST2(4);
 #undef VP_FAST2
-	} else if(fast) {
-		const size_t ldsf = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + TH * TW + TW + TH + 8 + (o <= 2 ? 16 * TW : 0) + TH);
-		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
-#define VP_FAST(OO) \
-		do { \
-			if(a.debug) k_sat_fast<OO, true><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a); \
-			else k_sat_fast<OO, false><<<grid, 256, ldsf, s>>>(fin, sat, graddot_out, a); \
-		} while(0)
-		if(o == 1) VP_FAST(1);
-		else if(o == 2) VP_FAST(2);
-		else if(o == 3) VP_FAST(3);
-		else VP_FAST(4);
-#undef VP_FAST
+	} else if(fused) {
+		if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sat_tiled<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		k_sat_tiled<true><<<grid, 256, lds, s>>>(in, sat, graddot_out, a);
 	} else {
-#define VP_TILED_LAUNCH(M) \
-	do { \
-		if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sat_tiled<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-		k_sat_tiled<M><<<grid, 256, lds, s>>>(in, sat, graddot_out, a); \
-	} while(0)
-	if(!fused) VP_TILED_LAUNCH(0);
-	else if(!pipe) VP_TILED_LAUNCH(-1);
-	else VP_TILED_LAUNCH(1);
-#undef VP_TILED_LAUNCH
+		k_sat_tiled<false><<<grid, 256, lds, s>>>(in, sat, graddot_out, a);
 	}
-	VP_TRY(vp_launch_ok("tiled sat"));
-	if(a.debug & 4) { // look-back statistics (debug only): windows, re-polls, chains, predecessors visited
-		uint32_t st[4];
-		VP_CHECK_HIP(hipStreamSynchronize(s));
-		VP_CHECK_HIP(hipMemcpy(st, a.ctrl + 8, sizeof(st), hipMemcpyDeviceToHost));
-		fprintf(stderr, "[sat-debug] chains %u windows %u repolls %u predecessors %u\n", st[2], st[0], st[1], st[3]);
-		VP_CHECK_HIP(hipMemset(a.ctrl + 8, 0, sizeof(st)));
-	}
-	if(a.debug & 8) { // in-kernel phase stamps (debug only; shader cycles summed over workgroups, wave 0 then wave 3)
-		unsigned long long acc[16];
-		VP_CHECK_HIP(hipStreamSynchronize(s));
-		VP_CHECK_HIP(hipMemcpy(acc, a.ctrl + 16 + 16 * batch, sizeof(acc), hipMemcpyDeviceToHost));
-		const double n = (double)a.nTiles;
-		fprintf(stderr, "[sat-phase] cycles/tile wave0: A(wait tile) %.0f  B %.0f  C/D(look-back) %.0f  barrier %.0f  E %.0f | wave3: A %.0f  B %.0f  C/D(dma issue) %.0f  barrier %.0f  E %.0f\n",
-				acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[8] / n, acc[9] / n, acc[10] / n, acc[11] / n, acc[12] / n);
-		fprintf(stderr, "[sat-phase] fast kernel split of B, wave0: compute %.0f  barrier %.0f  T16+prefetch issue %.0f | wave3: %.0f %.0f %.0f\n", acc[5] / n, acc[6] / n, acc[7] / n, acc[13] / n, acc[14] / n, acc[15] / n);
-		VP_CHECK_HIP(hipMemset(a.ctrl + 16 + 16 * batch, 0, sizeof(acc)));
-	}
-	return VP_OK;
+	return vp_launch_ok("tiled sat");
 }
