@@ -11,15 +11,19 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
 # host side: strict IEEE binary32 as well (the hypothesis stage is float arithmetic whose order is part of the restatement)
 CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -Wall -pthread -ffp-contract=off -fno-fast-math
 
-HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
-HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) include/vp_hip.h
+HIP_SRCS := $(filter-out %/vp_multi.hip,$(wildcard $(PKG)/csrc/*.hip))
+HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) include/vp_hip.h include/vp_multi.h
 HOST_SRCS := $(PKG)/host/synth.cpp $(PKG)/host/geometry.cpp $(wildcard $(PKG)/host/blobs/*.cpp)
 FACADE_SRCS := $(PKG)/host/frame_loop.cpp $(PKG)/host/Resources.cpp $(PKG)/host/opencl.cpp
 
 .PHONY: all hip host oracle facade clean
 all: hip host oracle facade
 
-hip: $(PKG)/libvp_hip.so
+hip: $(PKG)/libvp_hip.so $(PKG)/libvp_multi.so
+# multi-GPU end (include/vp_multi.h): one process, RCCL all-gather of the per-step records; kept out of libvp_hip.so so that the
+# single-GPU library does not depend on librccl
+$(PKG)/libvp_multi.so: $(PKG)/csrc/vp_multi.hip $(HIP_HDRS) $(PKG)/libvp_hip.so
+	$(HIPCC) $(HIPFLAGS) -I$(PKG)/csrc -shared -o $@ $(PKG)/csrc/vp_multi.hip -L$(PKG) -lvp_hip -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 $(PKG)/libvp_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
 
@@ -36,12 +40,12 @@ $(PKG)/host/vp_frame_loop: $(FACADE_SRCS) $(wildcard $(PKG)/host/*.h) $(PKG)/lib
 	g++ $(CXXFLAGS) -o $@ $(FACADE_SRCS) -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
 # many feeds on one GPU, C++ on the C ABI alone (vp_frame + read-back + vph_detect_batch, CPU stage overlapped with the next step)
-$(PKG)/host/vp_feeds: $(PKG)/host/feeds_main.cpp include/vp_hip.h include/vp_host.h $(PKG)/libvp_hip.so $(PKG)/libvp_host.so
-	g++ $(CXXFLAGS) -o $@ $(PKG)/host/feeds_main.cpp -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+$(PKG)/host/vp_feeds: $(PKG)/host/feeds_main.cpp $(PKG)/host/feeds_multi.cpp include/vp_hip.h include/vp_multi.h include/vp_host.h $(PKG)/libvp_hip.so $(PKG)/libvp_multi.so $(PKG)/libvp_host.so
+	g++ $(CXXFLAGS) -o $@ $(PKG)/host/feeds_main.cpp $(PKG)/host/feeds_multi.cpp -L$(PKG) -lvp_multi -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -s -C oracle oracle ref
 
 clean:
-	rm -f $(PKG)/libvp_hip.so $(PKG)/libvp_host.so $(PKG)/host/vp_frame_loop $(PKG)/host/vp_feeds
+	rm -f $(PKG)/libvp_hip.so $(PKG)/libvp_multi.so $(PKG)/libvp_host.so $(PKG)/host/vp_frame_loop $(PKG)/host/vp_feeds
 	$(MAKE) -s -C oracle clean

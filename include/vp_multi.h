@@ -1,0 +1,51 @@
+/*
+ * vp_multi.h -- C ABI of the multi-GPU end of the hot path (libvp_multi.so): ONE process, one VpContext per MI355X, camera
+ * feeds sharded over the devices, and the only exchange the path has -- the gather of the fixed-size detection records of a
+ * step -- as one RCCL all-gather per step on per-device streams, overlapped with the next step's kernels.
+ *
+ * Replaces: the reference runs one OS process per camera and exchanges SSL_WrapperPackets over UDP multicast
+ * (src/udpsocket.cpp:94-100 send, :147-163 receive; README.md:68-71 camera_amount / cam_id tiling).  On one node the same
+ * information is the blob records each device's vp_frame produced; every device receives every device's records
+ * (ncclCommInitAll + ncclAllGather on uint8, equal counts, latency-bound).
+ *
+ * Record block of one device and step (what vp_record_layout describes; vp_frame writes straight into it, nothing is packed):
+ *     [counter: batch x 3 int32, padded to 256 B][matches: batch x max_matches x 22 B, padded][idx: batch x max_matches x uint32, padded]
+ *
+ * Errors: VpStatus + vp_last_error() as in vp_hip.h.  No CPU fallback: without RCCL and a HIP device creation fails.
+ */
+#ifndef VP_MULTI_H
+#define VP_MULTI_H
+
+#include "vp_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct VpGather VpGather;
+
+/* Byte offsets of the three arrays inside one device's record block; returns the block size (a multiple of 256). */
+size_t vp_record_layout(int batch, int max_matches, size_t* off_counter, size_t* off_matches, size_t* off_idx);
+
+/* One communicator per device (ncclCommInitAll over devices[0..n)), one gather stream per device, n_slots (1..4) send / receive
+ * buffer pairs per device so that the gather of step k runs beside the kernels of step k + 1. */
+int vp_gather_create(int n_devices, const int* devices, size_t bytes_per_device, int n_slots, VpGather** out);
+void vp_gather_destroy(VpGather* g);
+int vp_gather_devices(const VpGather* g);
+
+/* Device pointers (memory of devices[rank]): the block this rank contributes, and the n_devices blocks it receives (rank-major). */
+void* vp_gather_send(VpGather* g, int rank, int slot);
+void* vp_gather_recv(VpGather* g, int rank, int slot);
+
+/* Start the all-gather of `slot`: on every device it begins once the work queued so far on ctx[rank] / stream[rank] has finished
+ * (event dependency, no host wait) and runs on that device's gather stream.  One grouped RCCL call over all devices. */
+int vp_gather_start(VpGather* g, int slot, VpContext* const* ctx, const int* stream);
+
+/* Block the host until the gather of `slot` has completed on every device (its send block may then be overwritten, its receive
+ * blocks read).  A slot that was never started returns at once. */
+int vp_gather_wait(VpGather* g, int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_MULTI_H */

@@ -42,6 +42,28 @@ def test_libraries_export_every_declared_symbol(built):
             assert hasattr(hip, f), f
 
 
+def test_multi_gpu_library_exports_the_gather(built):
+    """include/vp_multi.h (one process, N devices, RCCL all-gather of the per-step records) lives in libvp_multi.so; libvp_hip.so
+    itself stays free of the RCCL dependency.  Without a GPU the constructor fails loudly."""
+    import torch  # noqa: F401  (one HIP runtime per process: the copy bundled with PyTorch, as capi.lib() does)
+    C.CDLL(os.path.join(PKG, "libvp_hip.so"), mode=C.RTLD_GLOBAL)
+    multi = C.CDLL(os.path.join(PKG, "libvp_multi.so"))
+    fns = declared_functions("vp_multi.h", "vp_")
+    assert {"vp_gather_create", "vp_gather_start", "vp_gather_wait", "vp_gather_send", "vp_gather_recv", "vp_record_layout", "vp_gather_destroy"} <= set(fns)
+    missing = [f for f in fns if not hasattr(multi, f)]
+    assert not missing, missing
+    assert "rccl" in subprocess.run(["ldd", os.path.join(PKG, "libvp_multi.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in subprocess.run(["ldd", os.path.join(PKG, "libvp_hip.so")], capture_output=True, text=True).stdout
+    multi.vp_record_layout.restype = C.c_size_t
+    oc, om, oi = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    total = multi.vp_record_layout(3, 2000, C.byref(oc), C.byref(om), C.byref(oi))
+    assert oc.value == 0 and om.value == 256 and oi.value == 256 + 132096 and total == oi.value + 24064 and total % 256 == 0
+    if not torch.cuda.is_available():
+        g = C.c_void_p()
+        dev = (C.c_int * 1)(0)
+        assert multi.vp_gather_create(1, dev, C.c_size_t(total), 2, C.byref(g)) == -5  # VP_ERR_NODEVICE
+
+
 def test_host_library_exports_the_detection_stage(built):
     """include/vp_host.h (blob list -> SSL_DetectionFrame -> wire bytes) lives in libvp_host.so, which needs no GPU."""
     host = C.CDLL(os.path.join(PKG, "libvp_host.so"))
@@ -54,7 +76,7 @@ def test_host_library_exports_the_detection_stage(built):
 
 
 def test_product_does_not_link_the_oracle(built):
-    for so in ("libvp_hip.so", "libvp_host.so"):
+    for so in ("libvp_hip.so", "libvp_host.so", "libvp_multi.so"):
         out = subprocess.run(["ldd", os.path.join(PKG, so)], capture_output=True, text=True).stdout
         assert "oracle" not in out and "vpref" not in out
     for dirpath, _, files in os.walk(PKG):

@@ -224,14 +224,7 @@ RESAMPLE_BATCH_CASES = [
 def rs_tile_mapping(request):
     """The staged resampling kernels pick XCD-contiguous tile bands for large frames only; force both mappings on the small test
     frames as well (the tile count per frame group is then not a multiple of 8: the remap must stay a bijection)."""
-    old = os.environ.get("VP_RS_XCD")
-    if request.param != "auto":
-        os.environ["VP_RS_XCD"] = "1" if request.param == "xcd_bands" else "0"
-    yield request.param
-    if old is None:
-        os.environ.pop("VP_RS_XCD", None)
-    else:
-        os.environ["VP_RS_XCD"] = old
+    return {"auto": -1, "xcd_bands": 1, "plain": 0}[request.param]
 
 
 @pytest.mark.parametrize("cfg,B", RESAMPLE_BATCH_CASES, ids=[c.name for c, _ in RESAMPLE_BATCH_CASES])
@@ -239,6 +232,7 @@ def rs_tile_mapping(request):
 def test_resample_mapped_batches(gpu, port, cfg, B, mode, rs_tile_mapping):
     """Coordinate-map resampling over whole batches (the staged LDS kernel for Bayer + BILINEAR_RTZ) against the CPU oracle, per frame."""
     capi, ctx, torch = gpu
+    ctx.tune("resample_xcd_bands", rs_tile_mapping)
     model = cfg.model()
     model_o = O.CameraModel.from_array(np.frombuffer(bytes(model), np.uint8))
     raws = [cfg.synth(300 + 7 * i) for i in range(B)]
@@ -249,8 +243,11 @@ def test_resample_mapped_batches(gpu, port, cfg, B, mode, rs_tile_mapping):
     d_map = torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda")
     ctx.resample_map(model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, d_map)
     d_flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
-    ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, d_map, mode, cfg.fw, cfg.fh, B, d_flat)
-    ctx.sync()
+    try:
+        ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, d_map, mode, cfg.fw, cfg.fh, B, d_flat)
+        ctx.sync()
+    finally:
+        ctx.tune("resample_xcd_bands", -1)
     got = host(d_flat)
     for i in range(B):
         planes = port.raw2quad(raws[i], cfg.layout, cfg.qw, cfg.qh)
@@ -323,10 +320,11 @@ def test_colour_kernels_batches_and_odd_heights(gpu, port):
 
 
 @pytest.mark.parametrize("shape", [(64, 5), (64, 64), (128, 70), (192, 129), (256, 63), (66, 64), (130, 129), (150, 98), (1000, 70), (63, 40), (2, 3)], ids=lambda s: f"{s[0]}x{s[1]}")
-@pytest.mark.parametrize("o", [1, 2, 3, 4])
+@pytest.mark.parametrize("o", [0, 1, 2, 3, 4, 6])
 def test_fast_sat_edge_shapes(gpu, port, shape, o):
-    """The single-pass fast kernels on awkward shapes: one tile column, fewer rows than the halo, heights that overhang the last
-    tile row, with and without halo strips, with and without the gradDot view."""
+    """The single-pass kernels on awkward shapes: one tile column, fewer rows than the halo, heights that overhang the last tile
+    row, with and without halo strips, with and without the gradDot view, at 5 and 6 resident workgroups per CU (offsets 1..4 run
+    the fast kernel, 0 and 6 the generic one)."""
     capi, ctx, torch = gpu
     w, h = shape
     rng = np.random.default_rng(w * 1000 + h * 10 + o)
@@ -337,13 +335,12 @@ def test_fast_sat_edge_shapes(gpu, port, shape, o):
     want_gd = [port.graddot(flat[i], o) for i in range(B)]
     want_sat = [g.astype(np.int64).cumsum(0).cumsum(1).astype(np.int32) for g in want_gd]
     nbytes = ctx.halo_strip_bytes(w, h, o)
-    assert (nbytes > 0) == (w % 64 == 0)  # widths that are not a multiple of 64 run the fast kernel without strips
+    assert (nbytes > 0) == (w % 64 == 0 and 1 <= o <= 4)  # other widths / offsets run without strips
     d_strips = torch.zeros((B, max(nbytes, 4) // 4), dtype=torch.int32, device="cuda")
     if nbytes:
         ctx.halo_strips(d_flat, w, h, o, B, d_strips)
-    import os
-    for gen, with_strips, with_gd in [(g, s_, d) for g in ("1", "0") for s_ in ((False, True) if nbytes else (False,)) for d in (False, True)]:
-        os.environ["VP_SAT_V2"] = gen  # both generations of the fast kernel (read by the library at every launch)
+    for gen, with_strips, with_gd in [(g, s_, d) for g in (5, 6) for s_ in ((False, True) if nbytes else (False,)) for d in (False, True)]:
+        ctx.tune("sat_workgroups_per_cu", gen)  # the two register budgets the fast kernel is built for
         try:
             d_sat = torch.full((B, h, w), -7, dtype=torch.int32, device="cuda")
             d_gd = torch.zeros((B, h, w), dtype=torch.float32, device="cuda") if with_gd else None
@@ -353,7 +350,7 @@ def test_fast_sat_edge_shapes(gpu, port, shape, o):
                 ctx.graddot_sat(d_flat, w, h, o, B, capi.SAT_TILED, d_sat, d_gd)
             ctx.sync()
         finally:
-            os.environ.pop("VP_SAT_V2", None)
+            ctx.tune("sat_workgroups_per_cu", 5)
         for i in range(B):
             assert np.array_equal(host(d_sat[i]), want_sat[i]), (gen, with_strips, with_gd, i)
             if with_gd:

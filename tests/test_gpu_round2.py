@@ -1,0 +1,324 @@
+"""GPU parity tests added in round 2, all through the C ABI:
+  * BASELINE.json configs[2]: eight HIP streams of one context with eight different frames in flight before any
+    synchronisation (the one-loop-per-camera structure of main.cpp:262-317 on one device) -- every stream's flat, SAT, counters
+    and sorted blob records byte-identical to the CPU oracle;
+  * the fused circle + detect walker on awkward shapes and every specialised radius, against the oracle's circle + blobList;
+  * the bounded candidate list: a capacity smaller than the number of candidates still gives the exact list (rescan path);
+  * blocking map / unmap from other host threads while the main thread launches (rtpstreamer.cpp:177-181, snapshotwriter.cpp:52-54).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    capi = cases.vp.load_capi()
+    return capi, torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def oracle_frame(port, cfg, raw, mm):
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+    m, idx, cnt = port.frame(raw, cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                             cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+    sat, mx = port.sat_i32(s["graddot"])
+    assert mx < 2 ** 24
+    return dict(flat=s["flat"].copy(), sat=sat, m=m, idx=idx, cnt=cnt)
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["tiled", "twopass"])
+@pytest.mark.parametrize("batch", [1, 8])
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.CFG1], ids=lambda c: c.name)
+def test_config2_eight_streams_in_flight(env, port, cfg, batch, variant):
+    """One context, n_streams = 8, 8 x batch distinct frames; vp_frame is issued on all eight streams (three rounds, so that the per-stream
+    SAT epochs, ticket bases, coordinate-map keys and workspaces are all reused under overlap) before anything is synchronised."""
+    capi, torch = env
+    NS, mm = 8, cfg.max_matches
+    ctx = capi.Context(0, n_streams=NS)
+    try:
+        raws = [[cfg.synth(9000 + 31 * s + b) for b in range(batch)] for s in range(NS)]
+        want = [[oracle_frame(port, cfg, raws[s][b], mm) for b in range(batch)] for s in range(NS)]
+        bufs = []
+        for s in range(NS):
+            bufs.append(dict(raw=dev(torch, np.stack(raws[s])), flat=torch.zeros((batch, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"),
+                             sat=torch.zeros((batch, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"), m=torch.zeros((batch, mm * 22), dtype=torch.uint8, device="cuda"),
+                             idx=torch.zeros((batch, mm), dtype=torch.int32, device="cuda"), cnt=torch.full((batch, 3), -5, dtype=torch.int32, device="cuda")))
+        torch.cuda.synchronize()
+        p = capi.frame_params(cfg, sat_variant=variant, order=capi.ORDER_RASTER, use_coord_map=True)
+        for rnd in range(3):
+            for s in range(NS):  # all eight streams are loaded before any of them is waited for
+                b = bufs[s]
+                ctx.frame(p, b["raw"], batch, b["flat"], b["sat"], b["m"], b["cnt"], idx=b["idx"], stream=s)
+        ctx.sync()
+        for s in range(NS):
+            b = bufs[s]
+            flat, sat, m, idx, cnt = (b[k].cpu().numpy() for k in ("flat", "sat", "m", "idx", "cnt"))
+            for i in range(batch):
+                w_ = want[s][i]
+                assert np.array_equal(flat[i], w_["flat"]), (s, i, "flat")
+                assert np.array_equal(sat[i], w_["sat"]), (s, i, "sat")
+                assert np.array_equal(cnt[i], w_["cnt"]), (s, i, cnt[i], w_["cnt"])
+                n = min(int(cnt[i][0]), mm)
+                got = np.frombuffer(m[i].tobytes(), capi.MATCH_DTYPE)[:n]
+                assert np.array_equal(idx[i].view(np.uint32)[:n], w_["idx"]), (s, i, "RASTER order = sorted pixel indices")
+                assert got.tobytes() == w_["m"].tobytes(), (s, i, "records")
+    finally:
+        ctx.close()
+
+
+WALK_SHAPES = [(62, 40), (63, 17), (124, 64), (125, 33), (200, 150), (64, 3), (5, 7), (1, 1), (640, 70)]
+
+
+@pytest.mark.parametrize("r", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 1, 13])
+def test_circle_walk_edge_shapes(env, port, r):
+    """circle + detect straight from the SAT for every specialised radius (2..12: the register walker) and two others (the LDS
+    fallback), on shapes around the 62-column strips and short segments, at several rows-per-wavefront settings: the blobCenter
+    view, the counters and the sorted records equal the oracle's circle (satBlobCenter.cl) + matches (blobList.cl)."""
+    capi, torch = env
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        rng = np.random.default_rng(100 + r)
+        for (w, h), seg in zip(WALK_SHAPES, [0, 16, 16, 32, 64, 0, 16, 0, 128]):
+            B, mm, R = 2, 300, 2
+            gd = rng.integers(-900, 900, (B, h, w)).astype(np.float32)
+            # a few strong rings so that there are candidates, including at the borders and at strip boundaries
+            for _ in range(6):
+                cx, cy = int(rng.integers(0, w)), int(rng.integers(0, h))
+                gd[:, max(cy - 2, 0):cy + 3, max(cx - 2, 0):cx + 3] += rng.integers(500, 5000)
+            flat = rng.integers(0, 256, (B, h, w, 4), dtype=np.uint8)
+            flat[..., 3] = 255
+            sats = np.stack([port.sat_i32(gd[i])[0] for i in range(B)])
+            thr = 20.0
+            d_sat, d_flat = dev(torch, sats), dev(torch, flat)
+            ctx.tune("tail_segment_rows", seg)
+            for order in (capi.ORDER_RASTER, capi.ORDER_ATOMIC):
+                d_m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda")
+                d_idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+                d_cnt = torch.full((B, 3), -3, dtype=torch.int32, device="cuda")
+                d_bc = torch.full((B, h, w), np.nan, dtype=torch.float32, device="cuda")
+                with_bc = order == capi.ORDER_RASTER
+                ctx.blobcenter_list(d_flat, d_sat, w, h, B, r, thr, 0.0, R, mm, order, d_m, d_idx, d_cnt, d_bc if with_bc else None)
+                ctx.sync()
+                for i in range(B):
+                    bc = port.blobcenter_i32(sats[i], r)
+                    if with_bc:
+                        assert np.array_equal(d_bc[i].cpu().numpy(), bc, equal_nan=True), (w, h, r, "blobCenter view")
+                    wm, widx, wcnt = port.bloblist(flat[i], bc, thr, 0.0, R, mm)
+                    cnt = d_cnt[i].cpu().numpy()
+                    assert np.array_equal(cnt, wcnt), (w, h, r, seg, cnt, wcnt)
+                    gm, gi = capi.sorted_blobs(d_m[i].cpu().numpy(), d_idx[i].cpu().numpy().view(np.uint32), cnt, mm)
+                    if int(cnt[0]) <= mm:
+                        assert np.array_equal(gi, widx) and gm.tobytes() == wm.tobytes(), (w, h, r, seg)
+                        if order == capi.ORDER_RASTER:  # already sorted on the device
+                            assert np.array_equal(d_idx[i].cpu().numpy().view(np.uint32)[:len(widx)], widx)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("cap", [1, 7, 64])
+def test_candidate_list_overflow_is_exact(env, port, cap):
+    """More thresholded local maxima than candidate slots: the emit pass rescans the frame and the result is still the oracle's --
+    counters, the blob set, and (RASTER order) the order.  Both the fused path (from the SAT) and the path from a materialised
+    blobCenter image; a frame below the capacity travels in the same batch."""
+    capi, torch = env
+    cfg = cfgs.T_MID
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        mm = 400
+        raws = [cfg.synth(77), cfg.synth(78)]
+        s = [port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm) for _ in raws]
+        model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+        thr = 2.0  # low threshold: hundreds of candidates per frame
+        want = [port.frame(r, cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode, cfg.fw, cfg.fh,
+                           cfg.grad_offset, cfg.circle_radius, cfg.list_radius, thr, 0.5, mm, scratch=sc) for r, sc in zip(raws, s)]
+        assert all(int(w_[2][0]) + int(w_[2][1]) > 64 for w_ in want), "the case must overflow every tested capacity"
+        flat = np.stack([sc["flat"] for sc in s])
+        sats = np.stack([port.sat_i32(sc["graddot"])[0] for sc in s])
+        bcs = np.stack([sc["blobcenter"] for sc in s])
+        d_flat, d_sat, d_bc = dev(torch, flat), dev(torch, sats), dev(torch, bcs)
+        ctx.tune("candidate_capacity", cap)
+        for fused in (True, False):
+            for order in (capi.ORDER_RASTER, capi.ORDER_ATOMIC):
+                d_m = torch.zeros((2, mm * 22), dtype=torch.uint8, device="cuda")
+                d_idx = torch.zeros((2, mm), dtype=torch.int32, device="cuda")
+                d_cnt = torch.full((2, 3), -3, dtype=torch.int32, device="cuda")
+                for rep in range(2):  # twice: the self-cleaning counters must be back at zero after an overflowing launch
+                    if fused:
+                        ctx.blobcenter_list(d_flat, d_sat, cfg.fw, cfg.fh, 2, cfg.circle_radius, thr, 0.5, cfg.list_radius, mm, order, d_m, d_idx, d_cnt)
+                    else:
+                        ctx.bloblist(d_flat, d_bc, cfg.fw, cfg.fh, 2, thr, 0.5, cfg.list_radius, mm, order, d_m, d_idx, d_cnt)
+                    ctx.sync()
+                    for i in range(2):
+                        wm, widx, wcnt = want[i]
+                        cnt = d_cnt[i].cpu().numpy()
+                        assert np.array_equal(cnt, wcnt), (fused, order, rep, cnt, wcnt)
+                        gm, gi = capi.sorted_blobs(d_m[i].cpu().numpy(), d_idx[i].cpu().numpy().view(np.uint32), cnt, mm)
+                        if int(cnt[0]) <= mm:
+                            assert np.array_equal(gi, widx) and gm.tobytes() == wm.tobytes(), (fused, order, rep)
+    finally:
+        ctx.close()
+
+
+def test_map_and_unmap_from_other_threads_while_the_main_thread_launches(env, port):
+    """The reference maps NV12 buffers from its RTP encoder thread and images from its snapshot thread while the main loop keeps
+    launching (rtpstreamer.cpp:177-181, snapshotwriter.cpp:52-54).  Here: the main thread runs vp_frame in a loop on stream 0; thread A
+    fills, writes back and re-reads its own buffer on stream 1; threads B and C map the SAME image concurrently (first map allocates
+    the pinned shadow) on streams 2 and 3.  Every map returns what was written; the frames' results stay the oracle's."""
+    capi, torch = env
+    cfg = cfgs.T_MID
+    mm = cfg.max_matches
+    ctx = capi.Context(0, n_streams=4)
+    lib = capi.lib()
+    h = ctx.h
+    errors = []
+    try:
+        raw = cfg.synth(5)
+        want = oracle_frame(port, cfg, raw, mm)
+        d_raw = dev(torch, raw[None])
+        flat = torch.zeros((1, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+        sat = torch.zeros((1, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
+        m = torch.zeros((1, mm * 22), dtype=torch.uint8, device="cuda")
+        idx = torch.zeros((1, mm), dtype=torch.int32, device="cuda")
+        cnt = torch.zeros((1, 3), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        nbytes = ctx.nv12_bytes(320, 192)
+        buf = C.c_void_p()
+        assert lib.vp_buffer_create(h, C.c_size_t(nbytes), None, C.byref(buf)) == 0
+        img = C.c_void_p()
+        assert lib.vp_image_acquire(h, 2, 96, 64, C.byref(img)) == 0  # F32
+        pattern = np.arange(96 * 64, dtype=np.float32)
+        hp = C.c_void_p()
+        assert lib.vp_image_map(h, 3, img, 0, C.byref(hp)) == 0
+        C.memmove(hp, pattern.ctypes.data, pattern.nbytes)
+        assert lib.vp_image_unmap(h, 3, img, 1) == 0
+        stop = threading.Event()
+
+        def writer():  # thread A: its own NV12 buffer
+            try:
+                k = 0
+                while not stop.is_set():
+                    p_ = C.c_void_p()
+                    assert lib.vp_buffer_map(h, 1, buf, 0, C.byref(p_)) == 0
+                    C.memset(p_, k & 0xFF, nbytes)
+                    assert lib.vp_buffer_unmap(h, 1, buf, 1) == 0
+                    assert lib.vp_buffer_map(h, 1, buf, 1, C.byref(p_)) == 0
+                    got = np.ctypeslib.as_array(C.cast(p_, C.POINTER(C.c_uint8)), (nbytes,))
+                    assert int(got.min()) == int(got.max()) == (k & 0xFF), "NV12 buffer round trip"
+                    assert lib.vp_buffer_unmap(h, 1, buf, 0) == 0
+                    k += 1
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        def reader(stream):  # threads B, C: the same image
+            try:
+                while not stop.is_set():
+                    p_ = C.c_void_p()
+                    assert lib.vp_image_map(h, stream, img, 1, C.byref(p_)) == 0
+                    got = np.ctypeslib.as_array(C.cast(p_, C.POINTER(C.c_float)), (96 * 64,))
+                    assert np.array_equal(got, pattern), "image read-back"
+                    assert lib.vp_image_unmap(h, stream, img, 0) == 0
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=writer), threading.Thread(target=reader, args=(2,)), threading.Thread(target=reader, args=(3,))]
+        for t in threads:
+            t.start()
+        p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
+        for it in range(150):
+            ctx.frame(p, d_raw, 1, flat, sat, m, cnt, idx=idx, stream=0)
+            if it % 10 == 9:
+                ctx.sync(0)
+                c = cnt.cpu().numpy()[0]
+                assert np.array_equal(c, want["cnt"])
+        stop.set()
+        for t in threads:
+            t.join(30)
+        assert not errors, errors
+        ctx.sync()
+        n = min(int(want["cnt"][0]), mm)
+        assert np.array_equal(idx.cpu().numpy()[0].view(np.uint32)[:n], want["idx"])
+        assert np.array_equal(sat.cpu().numpy()[0], want["sat"])
+        assert lib.vp_buffer_destroy(h, buf) == 0 and lib.vp_image_release(h, img) == 0
+    finally:
+        ctx.close()
+
+
+def test_native_multi_gpu_feeds_gather_through_rccl(port):
+    """host/vp_feeds --gpus N (N = every visible device; 1 on the test box): one process, one context per device, vp_frame writing straight
+    into each device's record block, one grouped ncclAllGather per step through real RCCL (include/vp_multi.h).  The program checks that
+    every device received every owner's block byte for byte; here the gathered counters are additionally held to the CPU oracle's for
+    the same feed seeds (vision-processor_amd/feeds.py feed_seed)."""
+    import json
+    import os
+    import subprocess
+    import torch
+    n = torch.cuda.device_count()
+    exe = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_feeds")
+    envv = dict(os.environ)
+    envv["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + envv.get("LD_LIBRARY_PATH", "")
+    feeds = 2
+    out = subprocess.run([exe, "--gpus", str(n), str(feeds), "3", "1", "--verify"], capture_output=True, text=True, timeout=600, env=envv)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["gpus"] == n and r["gather_verified"] is True and "ncclAllGather" in r["gather"]
+    cfg = cfgs.CFG2
+    big = O.Port(threads=8)
+    for g in range(min(n, 2)):
+        for i in range(feeds):
+            want = oracle_frame(big, cfg, cfg.synth(cases.vp.feeds.feed_seed(g, i)), cfg.max_matches)
+            assert r["counters"][g][i] == [int(v) for v in want["cnt"]], (g, i)
+
+
+def test_gather_abi_in_process(env):
+    """include/vp_multi.h through ctypes: N = visible devices, two slots, blocks filled by device copies on the contexts' streams; after
+    vp_gather_start / vp_gather_wait every device's receive area holds all blocks in rank order."""
+    capi, torch = env
+    import os
+    n = torch.cuda.device_count()
+    lib = capi.lib()
+    multi = C.CDLL(os.path.join(cases.ROOT, "vision-processor_amd", "libvp_multi.so"))
+    multi.vp_gather_send.restype = C.c_void_p
+    multi.vp_gather_recv.restype = C.c_void_p
+    multi.vp_record_layout.restype = C.c_size_t
+    nbytes = multi.vp_record_layout(2, 64, None, None, None)
+    assert nbytes > 0 and nbytes % 256 == 0
+    ctxs = [capi.Context(d, n_streams=2) for d in range(n)]
+    g = C.c_void_p()
+    devs = (C.c_int * n)(*range(n))
+    assert multi.vp_gather_create(n, devs, C.c_size_t(nbytes), 2, C.byref(g)) == 0, lib.vp_last_error()
+    try:
+        harr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        for slot in (0, 1, 0):
+            blocks = [np.random.default_rng(17 * slot + r).integers(0, 256, nbytes, dtype=np.uint8) for r in range(n)]
+            for r in range(n):
+                ctxs[r].h2d(multi.vp_gather_send(g, r, slot), blocks[r], stream=slot)
+            streams = (C.c_int * n)(*([slot] * n))
+            assert multi.vp_gather_start(g, slot, harr, streams) == 0, lib.vp_last_error()
+            assert multi.vp_gather_wait(g, slot) == 0
+            for r in range(n):
+                got = ctxs[r].d2h(multi.vp_gather_recv(g, r, slot), (n, nbytes), np.uint8, stream=slot)
+                for q in range(n):
+                    assert np.array_equal(got[q], blocks[q]), (slot, r, q)
+        # a context on the wrong device is refused
+        if n >= 2:
+            swapped = (C.c_void_p * n)(*[c.h for c in reversed(ctxs)])
+            assert multi.vp_gather_start(g, 0, swapped, streams) != 0
+    finally:
+        multi.vp_gather_destroy(g)
+        for c in ctxs:
+            c.close()

@@ -130,6 +130,10 @@ class Context:
     def sync(self, stream=-1):
         self._ck(self.l.vp_sync(self.h, int(stream)))
 
+    def tune(self, key: str, value: int):
+        """vp_ctx_tune: result-neutral knobs (tile mappings, resident workgroups, list capacity); the library reads no environment variable."""
+        self._ck(self.l.vp_ctx_tune(self.h, key.encode(), int(value)))
+
     # ---- memory -----------------------------------------------------------------------------------------------------
     def malloc(self, nbytes) -> int:
         p = C.c_void_p()

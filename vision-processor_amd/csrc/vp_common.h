@@ -24,17 +24,30 @@ struct VpWorkspace {
 	size_t bytes = 0;
 };
 
-// device buffer with a lazily allocated pinned shadow for the blocking map / unmap of opencl.h:115-152
+// device buffer with a lazily allocated pinned shadow for the blocking map / unmap of opencl.h:115-152.  The reference maps from
+// its RTP encoder and snapshot threads while the main thread launches (rtpstreamer.cpp:177-181, snapshotwriter.cpp:52-54): map /
+// unmap of one object are serialised by its mutex, different objects never share state.
 struct VpBuffer {
 	void* dev = nullptr;
 	void* host = nullptr;
 	size_t bytes = 0;
+	std::mutex mu;
 };
 // pooled 2-D image (opencl.cpp:108-122): tightly packed rows
 struct VpImage {
 	VpBuffer buf;
 	int format = 0, w = 0, h = 0;
 	bool in_use = false;
+};
+
+// Result-neutral tuning knobs (vp_ctx_tune): every value gives bit-identical output.  The library reads no environment variable.
+struct VpTuning {
+	int sat_workgroups_per_cu = 5; // resident workgroups per CU of the single-pass SAT (2..8; 5 and 6 have their own register budget)
+	int resample_xcd_bands = -1;   // staged resampling: XCD-contiguous tile bands; -1 = automatic (on for >= 4096 tiles per frame group)
+	int resample_float_stage = 1;  // staged Bayer resampling, BILINEAR_RTZ: box staged as floats (1) or bytes (0)
+	int resample_bgr_staged = 1;   // BGR8 sensors: staged kernel (1) or the generic mapped kernel (0)
+	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
+	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
 };
 
 struct VpContext {
@@ -50,6 +63,7 @@ struct VpContext {
 	int* host_flag[VP_MAX_STREAMS] = {};           // pinned, device-mapped word the SAT kernel raises on a look-back timeout
 	std::string device_name;
 	int cu_count = 0;
+	VpTuning tune;
 	bool events_on = false;
 	std::mutex mu;
 	std::vector<VpEventRec> events;

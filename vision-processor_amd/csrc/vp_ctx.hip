@@ -101,6 +101,32 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 
 extern "C" const char* vp_device_name(VpContext* ctx) { return ctx ? ctx->device_name.c_str() : ""; }
 
+extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
+	VP_REQUIRE(ctx && key, "vp_ctx_tune: null argument");
+	const std::string k(key);
+	if(k == "sat_workgroups_per_cu") {
+		VP_REQUIRE(value >= 2 && value <= 8, "vp_ctx_tune: sat_workgroups_per_cu %d out of range [2,8]", value);
+		ctx->tune.sat_workgroups_per_cu = value;
+	} else if(k == "resample_xcd_bands") {
+		VP_REQUIRE(value >= -1 && value <= 1, "vp_ctx_tune: resample_xcd_bands takes -1 (automatic), 0 or 1");
+		ctx->tune.resample_xcd_bands = value;
+	} else if(k == "resample_float_stage") {
+		ctx->tune.resample_float_stage = value != 0;
+	} else if(k == "resample_bgr_staged") {
+		ctx->tune.resample_bgr_staged = value != 0;
+	} else if(k == "candidate_capacity") {
+		VP_REQUIRE(value >= 0, "vp_ctx_tune: candidate_capacity must be >= 0 (0 = default)");
+		ctx->tune.candidate_capacity = value;
+	} else if(k == "tail_segment_rows") {
+		VP_REQUIRE(value >= 0 && value <= 4096, "vp_ctx_tune: tail_segment_rows out of range [0,4096]");
+		ctx->tune.tail_segment_rows = value;
+	} else {
+		vp_set_error("vp_ctx_tune: unknown key '%s'", key);
+		return VP_ERR_INVALID;
+	}
+	return VP_OK;
+}
+
 // a raised flag means a bounded look-back wait of the single-pass SAT expired: the results of that launch are invalid
 int vp_check_timeout(VpContext* ctx, int stream) {
 	int* f = ctx->host_flag[stream];
@@ -232,6 +258,7 @@ static int buffer_map(VpContext* ctx, int stream, VpBuffer& b, int read_back, vo
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(host, "null pointer");
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	std::lock_guard<std::mutex> g(b.mu);
 	if(!b.host) {
 		hipError_t e = hipHostMalloc(&b.host, b.bytes ? b.bytes : 1, hipHostMallocDefault);
 		if(e != hipSuccess) {
@@ -247,6 +274,7 @@ static int buffer_map(VpContext* ctx, int stream, VpBuffer& b, int read_back, vo
 static int buffer_unmap(VpContext* ctx, int stream, VpBuffer& b, int write_back) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	std::lock_guard<std::mutex> g(b.mu);
 	if(write_back) {
 		VP_REQUIRE(b.host, "unmap of a buffer that was never mapped");
 		VP_CHECK_HIP(hipMemcpyAsync(b.dev, b.host, b.bytes, hipMemcpyHostToDevice, ctx->streams[stream]));

@@ -11,6 +11,10 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 		int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips);
 int vp_resample_impl(VpContext* ctx, int stream, const uint8_t* src, bool from_raw, int layout, int qw, int qh, const VpCameraModel* model,
 		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips);
+int vp_sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name, const uint32_t* strips,
+		int32_t* zero3, bool* zeroed);
+int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
+		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed);
 
 extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
 	VP_TRY(vp_check_ctx(ctx, stream));
@@ -47,7 +51,13 @@ extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, cons
 	} else {
 		VP_TRY(vp_resample_impl(ctx, stream, raw, true, p->layout, p->qw, p->qh, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->sampler_mode, p->fw, p->fh, batch, b->flat, strips));
 	}
-	VP_TRY(vp_graddot_sat_strips(ctx, stream, b->flat, strips.base, p->fw, p->fh, p->grad_offset, batch, p->sat_variant, b->sat, b->graddot));
-	return vp_blobcenter_list(ctx, stream, b->flat, b->sat, p->fw, p->fh, batch, p->circle_radius, p->circ_threshold, p->min_score, p->list_radius, p->max_matches, p->order,
-			b->matches, b->idx, b->counter, b->blobcenter);
+	VP_REQUIRE(p->fw > 0 && p->fh > 0 && batch > 0 && batch <= 65535 && p->list_radius >= 0 && p->circle_radius >= 0 && p->max_matches > 0 && (size_t)p->fw * p->fh < (size_t(1) << 31), "vp_frame: bad shape");
+	VP_REQUIRE(p->order == VP_ORDER_ATOMIC || p->order == VP_ORDER_RASTER, "vp_frame: bad order");
+	VP_REQUIRE((reinterpret_cast<uintptr_t>(b->matches) & 1) == 0, "vp_frame: matches must be 2-byte aligned");
+	// four launches per call: [raw2quad+resampling] -> [gradientDot+SAT, which also clears the list counters] -> [circle+detect] -> [emit (+ sort)]
+	bool zeroed = false;
+	VP_TRY(vp_sat_common(ctx, stream, b->flat, true, p->fw, p->fh, p->grad_offset, batch, p->sat_variant, b->sat, b->graddot, "gradientDot+sat", strips.base, b->counter, &zeroed));
+	VpStageTimer t(ctx, stream, "satBlobCenter+blobList");
+	return vp_list_from_blobcenter(ctx, stream, b->flat, nullptr, b->sat, p->circle_radius, b->blobcenter, p->fw, p->fh, batch, p->circ_threshold, p->min_score, p->list_radius, p->max_matches, p->order,
+			b->matches, b->idx, b->counter, zeroed);
 }

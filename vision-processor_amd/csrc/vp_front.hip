@@ -814,9 +814,9 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	// staged kernel: Bayer + BILINEAR_RTZ with dword-aligned sensor rows; a frame group's spans must fit the 32-bit buffer offsets
 	const size_t span = (size_t)RESAMPLE_FPT * std::max(std::max(frame_bytes, (size_t)fw * fh * 4), strips.base ? strips.frame_words * 4 : (size_t)0);
 	if(layout == VP_LAYOUT_BGR && (qw & 3) == 0 && batch >= 2 && (size_t)RESAMPLE_FPT * frame_bytes < 0x7fffffffu && (reinterpret_cast<uintptr_t>(raw) & 3) == 0 &&
-			qw < 21845 && qh < 65536 && vp_div_up(fh, 4) <= 65535 && !(getenv("VP_RS_BGR") && atoi(getenv("VP_RS_BGR")) == 0)) {
+			qw < 21845 && qh < 65536 && vp_div_up(fh, 4) <= 65535 && ctx->tune.resample_bgr_staged) {
 		const dim3 grid3(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
-		const int xcd_map = getenv("VP_RS_XCD") ? atoi(getenv("VP_RS_XCD")) : (grid3.x * grid3.y >= 4096u); // see the Bayer launch below
+		const int xcd_map = ctx->tune.resample_xcd_bands >= 0 ? ctx->tune.resample_xcd_bands : (grid3.x * grid3.y >= 4096u); // see the Bayer launch below
 		if(sampler_mode == VP_SAMPLER_NEAREST) k_resample_staged_bgr<VP_SAMPLER_NEAREST><<<grid3, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map);
 		else k_resample_staged_bgr<VP_SAMPLER_BILINEAR_RTZ><<<grid3, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map);
 		return vp_launch_ok("raw2quad+resampling (staged, BGR)");
@@ -824,11 +824,11 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	if(layout != VP_LAYOUT_BGR && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
 			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
 		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
-		const bool flt = !(getenv("VP_RS_FLT") && atoi(getenv("VP_RS_FLT")) == 0); // float-staged variant (default; VP_RS_FLT=0 selects the byte-staged one for A/B)
+		const bool flt = ctx->tune.resample_float_stage != 0; // float-staged variant (default; vp_ctx_tune "resample_float_stage" 0 selects the byte-staged one)
 		const int variant = sampler_mode == VP_SAMPLER_NEAREST ? 2 : (flt ? 1 : 0);
 		// XCD-contiguous tile bands for large frames (measured at 2048x1536: HBM reads 1.38 -> 0.60 GB per 128 frames, time unchanged;
-		// at 640x480 the bands unbalance the XCDs: 87 -> 99 us, so small grids keep the plain mapping).  VP_RS_XCD=0/1 forces it (A/B).
-		const int xcd_map = getenv("VP_RS_XCD") ? atoi(getenv("VP_RS_XCD")) : (grid.x * grid.y >= 4096u);
+		// at 640x480 the bands unbalance the XCDs: 87 -> 99 us, so small grids keep the plain mapping).  vp_ctx_tune "resample_xcd_bands" forces it.
+		const int xcd_map = ctx->tune.resample_xcd_bands >= 0 ? ctx->tune.resample_xcd_bands : (grid.x * grid.y >= 4096u);
 #define VP_RST(L, V) k_resample_staged<L, V><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map)
 		if(layout == VP_LAYOUT_RGGB) {
 			if(variant == 2) VP_RST(VP_LAYOUT_RGGB, 2);

@@ -128,28 +128,33 @@ int vp_sat_twopass(VpContext* ctx, int stream, const void* in, bool fused, int w
 	return vp_launch_ok("sat column pass");
 }
 
-int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out, const uint32_t* strips);
+int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out, const uint32_t* strips, int32_t* zero3);
 
-static int sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name, const uint32_t* strips = nullptr) {
+// zero3 (vp_frame only): the blob list's counter[3 x batch], cleared by the single-pass kernel's first workgroup per frame so that
+// the tail needs no clearing launch; *zeroed tells the caller whether that happened (the two-pass variant does not do it).
+int vp_sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name, const uint32_t* strips,
+		int32_t* zero3, bool* zeroed) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(in && sat && w > 0 && h > 0 && batch > 0 && batch <= 65535 && offset >= 0, "%s: bad arguments", name);
 	VP_REQUIRE(variant == VP_SAT_TILED || variant == VP_SAT_TWOPASS, "%s: unknown SAT variant %d", name, variant);
 	VP_REQUIRE((reinterpret_cast<uintptr_t>(in) & 3) == 0 && (reinterpret_cast<uintptr_t>(sat) & 3) == 0, "%s: buffers must be 4-byte aligned", name);
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, name);
+	if(zeroed) *zeroed = false;
 	if(variant == VP_SAT_TWOPASS) return vp_sat_twopass(ctx, stream, in, fused, w, h, offset, batch, sat, gd);
-	return vp_sat_tiled(ctx, stream, in, fused, w, h, offset, batch, sat, gd, strips);
+	if(zeroed) *zeroed = zero3 != nullptr;
+	return vp_sat_tiled(ctx, stream, in, fused, w, h, offset, batch, sat, gd, strips, zero3);
 }
 
 extern "C" int vp_sat(VpContext* ctx, int stream, const float* graddot, int w, int h, int batch, int variant, int32_t* sat) {
-	return sat_common(ctx, stream, graddot, false, w, h, 0, batch, variant, sat, nullptr, "sat");
+	return vp_sat_common(ctx, stream, graddot, false, w, h, 0, batch, variant, sat, nullptr, "sat", nullptr, nullptr, nullptr);
 }
 
 extern "C" int vp_graddot_sat(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, int variant, int32_t* sat, float* graddot_out) {
-	return sat_common(ctx, stream, flat, true, w, h, offset, batch, variant, sat, graddot_out, "gradientDot+sat");
+	return vp_sat_common(ctx, stream, flat, true, w, h, offset, batch, variant, sat, graddot_out, "gradientDot+sat", nullptr, nullptr, nullptr);
 }
 
 extern "C" int vp_graddot_sat_strips(VpContext* ctx, int stream, const uint8_t* flat, const uint32_t* strips, int w, int h, int offset, int batch, int variant,
 		int32_t* sat, float* graddot_out) {
-	return sat_common(ctx, stream, flat, true, w, h, offset, batch, variant, sat, graddot_out, "gradientDot+sat", strips);
+	return vp_sat_common(ctx, stream, flat, true, w, h, offset, batch, variant, sat, graddot_out, "gradientDot+sat", strips, nullptr, nullptr);
 }

@@ -49,6 +49,7 @@ struct TiledArgs {
 	int* host_flag; // pinned, device-mapped
 	VpStrips strips; // optional halo strips (base == nullptr: halo columns are read from flat)
 	int single;     // k_sat_fast2: as many workgroups as tiles per frame -- each takes ONE ticket and none in advance
+	int32_t* zero;  // optional: int[3 x batch] cleared by the first workgroup of each frame (the blob list's counters, main.cpp:283-288)
 };
 
 __device__ __forceinline__ u64 ld_granule(const u64* p) {
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 	int32_t* out = sat + frame;
 	const bool loader = tid == 3 * 64; // lane 0 of wave 3 owns the ticket queue
 
+	if(a.zero && blockIdx.x < (unsigned)a.batch && tid < 3) a.zero[3 * blockIdx.x + tid] = 0;
 	uint32_t pending = 0; // ticket requested one tile ahead
 	if(loader) {
 		const uint32_t t0 = atomicAdd(queue, 1u);
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	const size_t frame = (size_t)f * w * h;
 	const bool loader = tid == 3 * 64;
 
+	if(a.zero && blockIdx.x < (unsigned)a.batch && tid < 3) a.zero[3 * blockIdx.x + tid] = 0;
 	uint32_t pending = 0;
 	if(loader) {
 		const uint32_t t0 = atomicAdd(queue, 1u);
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 
 int vp_check_timeout(VpContext* ctx, int stream);
 
-int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out, const uint32_t* strips) {
+int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int32_t* sat, float* graddot_out, const uint32_t* strips, int32_t* zero3) {
 	hipStream_t s = ctx->streams[stream];
 	const int o = fused ? offset : 0;
 	VP_REQUIRE(o <= 32, "VP_SAT_TILED: gradient offset %d > 32 is not supported (LDS halo)", o);
@@ -671,6 +674,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	VP_REQUIRE(nt < (1ll << 30), "VP_SAT_TILED: too many tiles (%lld)", nt);
 	a.nTiles = (int)nt;
 	a.batch = batch;
+	a.zero = zero3;
 	const int rawRows = TH + 2 * o;
 	a.pitch = (rawRows * 2 * o + 3) & ~3; // halo array (dwords), 16-byte multiple
 	const size_t lds = sizeof(int) * ((size_t)rawRows * TW + a.pitch + TH * TW + NWAVES * TW + TW + TH + 8);

@@ -51,30 +51,37 @@ extern "C" int vp_blobcenter(VpContext* ctx, int stream, const int32_t* sat, int
 }
 
 // ---------------------------------------------------------------- blobList -----------------------------------------
+// Workspace of one list call (slot 0 of the stream).  The two counter arrays sit at the START of the workspace and are
+// SELF-CLEANING: the emit kernel's last workgroup of a frame puts cand_count / done back to zero, so no launch has to clear
+// them (the workspace is zero-filled when it is allocated; every layout keeps them at offset 0).
 struct ListScratch {
-	uint32_t* cand;       // batch x n   candidate pixel indices
-	int32_t* cand_count;  // batch
-	uint32_t* idx;        // batch x max  (internal idx when the caller passes none)
-	uint32_t* idx_tmp;    // batch x max
-	uint8_t* rec_tmp;     // batch x max x 22
-	float* blobcenter;    // batch x n, only when the fused entry point has to materialise it itself
+	int32_t* cand_count;  // batch   candidates found by the detect pass (may exceed cap: the emit pass then rescans the frame)
+	int32_t* done;        // batch   emit workgroups finished (last-workgroup-done pattern)
+	uint32_t* cand;       // batch x cap   candidate pixel indices
+	uint32_t* idx;        // batch x max  (append-order idx: RASTER order, or when the caller passes none)
+	uint8_t* rec_tmp;     // batch x max x 22   append-order records (RASTER order only)
+	int cap;              // candidate capacity per frame
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
-static int list_scratch(VpContext* ctx, int stream, size_t n, int batch, int max_matches, bool need_bc, ListScratch* s) {
-	const size_t b_cand = align256(sizeof(uint32_t) * n * batch), b_cnt = align256(sizeof(int32_t) * batch);
+// The candidate list is bounded: cap = max(4 * max_matches, 4096) entries per frame (vp_ctx_tune "candidate_capacity" overrides).
+// A frame with more thresholded local maxima than that is still processed exactly: the emit pass sees cand_count > cap and
+// rescans the frame itself instead of reading the list (slow, pathological inputs only).
+static int list_scratch(VpContext* ctx, int stream, int batch, int max_matches, ListScratch* s) {
+	const int cap = ctx->tune.candidate_capacity > 0 ? ctx->tune.candidate_capacity : (max_matches > 1024 ? 4 * max_matches : 4096);
+	const size_t b_cnt = align256(sizeof(int32_t) * 2 * batch), b_cand = align256(sizeof(uint32_t) * (size_t)cap * batch);
 	const size_t b_idx = align256(sizeof(uint32_t) * (size_t)max_matches * batch), b_rec = align256((size_t)22 * max_matches * batch);
-	const size_t b_bc = need_bc ? align256(sizeof(float) * n * batch) : 0;
 	void* base = nullptr;
-	VP_TRY(vp_workspace(ctx, stream, 0, b_cand + b_cnt + 2 * b_idx + b_rec + b_bc, &base));
+	VP_TRY(vp_workspace(ctx, stream, 0, b_cnt + b_cand + b_idx + b_rec, &base));
 	uint8_t* p = static_cast<uint8_t*>(base);
+	s->cand_count = reinterpret_cast<int32_t*>(p);
+	s->done = s->cand_count + batch;
+	p += b_cnt;
 	s->cand = reinterpret_cast<uint32_t*>(p); p += b_cand;
-	s->cand_count = reinterpret_cast<int32_t*>(p); p += b_cnt;
 	s->idx = reinterpret_cast<uint32_t*>(p); p += b_idx;
-	s->idx_tmp = reinterpret_cast<uint32_t*>(p); p += b_idx;
-	s->rec_tmp = p; p += b_rec;
-	s->blobcenter = need_bc ? reinterpret_cast<float*>(p) : nullptr;
+	s->rec_tmp = p;
+	s->cap = cap;
 	return VP_OK;
 }
 
@@ -82,23 +89,36 @@ __device__ __forceinline__ float bc_tap(const float* __restrict__ c, int w, int 
 	return c[(size_t)vp_clampi(y, 0, h - 1) * w + vp_clampi(x, 0, w - 1)];
 }
 
-// blobList.cl:37-55: threshold, 4-neighbour strict-'>' peak test
+// Wave-aggregated stream compaction (the blob list's atomic_inc of blobList.cl:87 happens later, once per surviving candidate): the
+// lanes holding a candidate are counted with a 64-bit ballot, lane 0 reserves that many slots with ONE atomic, and every lane takes
+// base + (set bits below it) (v_mbcnt_lo / _hi).  Must be called with all 64 lanes active.  Slots beyond `cap` are counted but not
+// written: the emit pass sees count > cap and rescans the frame instead.
+__device__ __forceinline__ void wave_append(bool is_cand, uint32_t pix, uint32_t* __restrict__ cand_frame, int32_t* __restrict__ count, int cap, int lane) {
+	const unsigned long long m = __ballot(is_cand);
+	if(m == 0) return; // wave-uniform
+	int base = 0;
+	if(lane == 0) base = atomicAdd(count, __popcll(m));
+	base = __builtin_amdgcn_readfirstlane(base);
+	const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+	if(is_cand && slot < cap) cand_frame[slot] = pix;
+}
+
+// blobList.cl:37-55: threshold, 4-neighbour strict-'>' peak test, on a materialised blobCenter image
 __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ circ, uint32_t* __restrict__ cand, int32_t* __restrict__ cand_count,
-		int32_t* __restrict__ counter, int w, int h, float thr) {
+		int32_t* __restrict__ counter, int w, int h, float thr, int cap) {
 	const int x = blockIdx.x * 64 + threadIdx.x;
 	const int y = blockIdx.y * 4 + threadIdx.y;
-	if(x >= w || y >= h) return;
 	const int z = blockIdx.z;
 	const size_t n = (size_t)w * h;
 	const float* c = circ + z * n;
-	const float v = c[(size_t)y * w + x];
-	if(v < thr) return;
-	if(bc_tap(c, w, h, x - 1, y) > v || bc_tap(c, w, h, x + 1, y) > v || bc_tap(c, w, h, x, y - 1) > v || bc_tap(c, w, h, x, y + 1) > v) {
-		atomicAdd(&counter[3 * z + 2], 1);
-		return;
-	}
-	const int slot = atomicAdd(&cand_count[z], 1);
-	cand[z * n + slot] = (uint32_t)(y * w + x);
+	const bool in = x < w && y < h;
+	const float v = in ? c[(size_t)y * w + x] : 0.f;
+	const bool above = in && !(v < thr);
+	bool peak = false;
+	if(above) peak = !(bc_tap(c, w, h, x - 1, y) > v || bc_tap(c, w, h, x + 1, y) > v || bc_tap(c, w, h, x, y - 1) > v || bc_tap(c, w, h, x, y + 1) > v);
+	const unsigned long long mr = __ballot(above && !peak);
+	if(mr != 0 && threadIdx.x == 0) atomicAdd(&counter[3 * z + 2], __popcll(mr));
+	wave_append(above && peak, (uint32_t)(y * w + x), cand + (size_t)z * cap, cand_count + z, cap, threadIdx.x);
 }
 
 __device__ __forceinline__ void store_match(uint8_t* dst, float x, float y, const uint32_t color[3], uint32_t center, float circ, float score) {
@@ -149,24 +169,31 @@ __device__ __forceinline__ float disc_score_wave(const uint32_t* __restrict__ f,
 
 // blobList.cl:57-102, one wavefront per candidate.  FROM_SAT: blobCenter was never materialised; the five values the record
 // needs (centre + 4 neighbours, clamp-to-edge) are recomputed from the SAT by lanes 0-4.
+// The LAST workgroup of a frame to finish (arrival counter `done`) sorts the frame's records by pixel index into the caller's
+// arrays when the order is RASTER, and puts the self-cleaning counters back to zero: no separate sort launch, no clearing launch.
 template<bool FROM_SAT>
 __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat, const void* __restrict__ src, const uint32_t* __restrict__ cand,
-		const int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, uint8_t* __restrict__ matches, uint32_t* __restrict__ idx_out,
-		int w, int h, float min_score, int radius, int max_matches, int circle_radius) {
+		int32_t* __restrict__ cand_count, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work, uint32_t* __restrict__ idx_work,
+		int w, int h, float thr, float min_score, int radius, int max_matches, int circle_radius, int cap, int order,
+		uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+	__shared__ uint32_t tile[256];
+	__shared__ int s_last;
 	const int z = blockIdx.y;
 	const size_t n = (size_t)w * h;
 	const uint32_t* f = flat + z * n;
 	const float* c = reinterpret_cast<const float*>(src) + z * n;
 	const int32_t* sat = reinterpret_cast<const int32_t*>(src) + z * n;
 	const int lane = threadIdx.x & 63;
+	const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
 	const int total = cand_count[z];
-	for(int k = blockIdx.x * 4 + (threadIdx.x >> 6); k < total; k += gridDim.x * 4) {
-		const uint32_t pix = cand[z * n + k];
+	const float cdiv = (float)(circle_radius * circle_radius);
+
+	auto emit_one = [&](uint32_t pix) { // all 64 lanes
 		const int px = (int)(pix % (uint32_t)w), py = (int)(pix / (uint32_t)w);
 		float v, nx, qx, ny, qy;
 		if(FROM_SAT) {
 			const int dx = lane == 1 ? -1 : (lane == 2 ? 1 : 0), dy = lane == 3 ? -1 : (lane == 4 ? 1 : 0);
-			const float mine = lane < 5 ? circle_at(sat, w, h, vp_clampi(px + dx, 0, w - 1), vp_clampi(py + dy, 0, h - 1), circle_radius, (float)(circle_radius * circle_radius)) : 0.f;
+			const float mine = lane < 5 ? circle_at(sat, w, h, vp_clampi(px + dx, 0, w - 1), vp_clampi(py + dy, 0, h - 1), circle_radius, cdiv) : 0.f;
 			v = __shfl(mine, 0, 64); nx = __shfl(mine, 1, 64); qx = __shfl(mine, 2, 64); ny = __shfl(mine, 3, 64); qy = __shfl(mine, 4, 64);
 		} else {
 			v = c[pix];
@@ -175,77 +202,209 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 		}
 		uint32_t color[3];
 		const float score = disc_score_wave(f, w, h, px, py, radius, v, color);
-		if(lane != 0) continue;
-		if(score < min_score) { // :79-82 (NaN is kept)
-			atomicAdd(&counter[3 * z + 1], 1);
-			continue;
+		if(lane == 0) {
+			if(score < min_score) { // :79-82 (NaN is kept)
+				atomicAdd(&counter[3 * z + 1], 1);
+			} else {
+				const int i = atomicAdd(&counter[3 * z], 1); // :87
+				if(i < max_matches) {                        // :88-89
+					const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
+					const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
+					store_match(rec_work + ((size_t)z * max_matches + i) * 22, mx, my, color, f[pix], v, score);
+					idx_work[(size_t)z * max_matches + i] = pix;
+				}
+			}
 		}
-		const int i = atomicAdd(&counter[3 * z], 1); // :87
-		if(i >= max_matches) continue;               // :88-89
-		const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
-		const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
-		store_match(matches + ((size_t)z * max_matches + i) * 22, mx, my, color, f[pix], v, score);
-		idx_out[(size_t)z * max_matches + i] = pix;
-	}
-}
+	};
 
-// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique)
-__global__ __launch_bounds__(256) void k_rank_scatter(const uint8_t* __restrict__ rec, const uint32_t* __restrict__ idx, const int32_t* __restrict__ counter,
-		uint8_t* __restrict__ rec_tmp, uint32_t* __restrict__ idx_tmp, int max_matches) {
-	__shared__ uint32_t tile[256];
-	const int z = blockIdx.y;
-	const int n = min(counter[3 * z], max_matches);
-	const int t = blockIdx.x * 256 + threadIdx.x;
-	const uint32_t* id = idx + (size_t)z * max_matches;
-	const uint32_t mine = t < n ? id[t] : 0;
-	int rank = 0;
-	for(int j0 = 0; j0 < n; j0 += 256) {
-		const int j = j0 + threadIdx.x;
-		tile[threadIdx.x] = j < n ? id[j] : 0xFFFFFFFFu;
-		__syncthreads();
-		const int m = min(256, n - j0);
-		for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
-		__syncthreads();
+	if(total <= cap) {
+		for(int k = gw; k < total; k += nw) emit_one(cand[(size_t)z * cap + k]);
+	} else {
+		// More candidates than list slots (pathological frame): the list is incomplete, so find the candidates again -- 64 pixels per
+		// wavefront step, the same threshold + peak test on the same values, then one emit per set ballot bit.  Exact, just slow.
+		for(size_t p0 = (size_t)gw * 64; p0 < n; p0 += (size_t)nw * 64) {
+			const size_t pix = p0 + lane;
+			const bool in = pix < n;
+			const int px = in ? (int)(pix % (uint32_t)w) : 0, py = in ? (int)(pix / (uint32_t)w) : 0;
+			bool is = false;
+			if(in) {
+				if(FROM_SAT) {
+					const float v = circle_at(sat, w, h, px, py, circle_radius, cdiv);
+					if(!(v < thr))
+						is = !(circle_at(sat, w, h, max(px - 1, 0), py, circle_radius, cdiv) > v || circle_at(sat, w, h, min(px + 1, w - 1), py, circle_radius, cdiv) > v ||
+						       circle_at(sat, w, h, px, max(py - 1, 0), circle_radius, cdiv) > v || circle_at(sat, w, h, px, min(py + 1, h - 1), circle_radius, cdiv) > v);
+				} else {
+					const float v = c[pix];
+					if(!(v < thr)) is = !(bc_tap(c, w, h, px - 1, py) > v || bc_tap(c, w, h, px + 1, py) > v || bc_tap(c, w, h, px, py - 1) > v || bc_tap(c, w, h, px, py + 1) > v);
+				}
+			}
+			unsigned long long m = __ballot(is);
+			while(m != 0) { // wave-uniform
+				const int bpos = __ffsll((long long)m) - 1;
+				m &= m - 1;
+				emit_one((uint32_t)(p0 + (size_t)bpos));
+			}
+		}
 	}
-	if(t < n) {
-		const uint16_t* src = reinterpret_cast<const uint16_t*>(rec + ((size_t)z * max_matches + t) * 22);
-		uint16_t* dst = reinterpret_cast<uint16_t*>(rec_tmp + ((size_t)z * max_matches + rank) * 22);
+
+	// ---- arrival: every record store of this workgroup is visible device-wide before its arrival is counted ------------------
+	__threadfence();
+	__syncthreads();
+	if(threadIdx.x == 0) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		s_last = atomicAdd(&done[z], 1) == (int)gridDim.x - 1;
+	}
+	__syncthreads();
+	if(!s_last) return;
+	__threadfence(); // acquire: the other workgroups' records and counters
+	if(threadIdx.x == 0) { // self-cleaning: every workgroup of this frame has read cand_count and arrived
+		cand_count[z] = 0;
+		done[z] = 0;
+	}
+	if(order != VP_ORDER_RASTER) return;
+	// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique)
+	const int nrec = min(__hip_atomic_load(&counter[3 * z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), max_matches);
+	const uint32_t* id = idx_work + (size_t)z * max_matches;
+	for(int t0 = 0; t0 < nrec; t0 += 256) {
+		const int t = t0 + (int)threadIdx.x;
+		const uint32_t mine = t < nrec ? id[t] : 0;
+		int rank = 0;
+		for(int j0 = 0; j0 < nrec; j0 += 256) {
+			const int j = j0 + (int)threadIdx.x;
+			tile[threadIdx.x] = j < nrec ? id[j] : 0xFFFFFFFFu;
+			__syncthreads();
+			const int m = min(256, nrec - j0);
+			for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
+			__syncthreads();
+		}
+		if(t < nrec) {
+			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + ((size_t)z * max_matches + t) * 22);
+			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + ((size_t)z * max_matches + rank) * 22);
 #pragma unroll
-		for(int k = 0; k < 11; k++) dst[k] = src[k];
-		if(idx_tmp) idx_tmp[(size_t)z * max_matches + rank] = mine;
+			for(int k = 0; k < 11; k++) dp[k] = sp[k];
+			if(idx_sorted) idx_sorted[(size_t)z * max_matches + rank] = mine;
+		}
 	}
 }
 
-__global__ __launch_bounds__(256) void k_zero2(int32_t* __restrict__ a, int na, int32_t* __restrict__ b, int nb) {
+__global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ a, int na) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if(i < na) a[i] = 0;
-	if(i < nb) b[i] = 0;
 }
 
-// circle + detect fused: the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge addressing (satBlobCenter.cl:20, H7),
-// blobCenter is computed for the 64x64 tile plus a 1-pixel ring into LDS, then thresholded / peak-tested (blobList.cl:37-55).
-// Out-of-image ring positions take the value of the clamped position, exactly what the clamped reads of the reference return.
-constexpr int FT_W = 64, FT_H = 64, FT_NT = 512; // tile and threads per workgroup (64x64: region / tile = 1.48, 64x32 was 1.72)
+// ---------------------------------------------------------------- circle + detect, fused --------------------------------------
+// satBlobCenter.cl:34-42 + the detection half of blobList.cl:37-55 straight from the SAT; blobCenter never reaches memory.
+//
+// All four quadrant sums of satBlobCenter.cl:37-40 are ONE box-sum image sampled at four offsets:
+//   Bx(u, v) = S(u+r-1, v+r-1) - S(u+r-1, v) - S(u, v+r-1) + S(u, v)        (every tap clamped on its own, as in the reference)
+//   pp(x, y) = Bx(x+1, y+1),  nn = Bx(x-r, y-r),  pn = -Bx(x+1, y-r),  np = -Bx(x-r, y+1)
+// and Bx separates into row differences: with  D1(row) = S(x+r, row) - S(x+1, row)  and  D2(row) = S(x-1, row) - S(x-r, row)
+//   pp = D1(y+r) - D1(y+1),   -Bx(x+1, y-r) = D1(y-r) - D1(y-1),   -Bx(x-r, y+1) = D2(y+1) - D2(y+r),   nn = D2(y-1) - D2(y-r).
+// So a lane that owns image column x and WALKS DOWN the rows needs four SAT values per row (columns x+r, x+1, x-1, x-r of row
+// y+r: coalesced dword loads with a scalar row offset, clamp-to-edge folded into the per-lane column offsets and the scalar row
+// index) and keeps the last 2r+1 values of D1 and D2 in registers: 4 loads + ~20 VALU instructions per pixel, no LDS, no barrier,
+// no index arithmetic in the loop.  Wrapping int32 differences are exact; min(min(pp,nn),min(pn,np)) is taken on the
+// integers and converted once (int -> float is monotonic, so the converted minimum is the minimum of the converted values).
+// The peak test needs blobCenter of the four neighbours: up / down are the lane's own previous / next row, left / right come from
+// the neighbouring lanes by DPP wave shifts.  A wavefront therefore covers 62 image columns (lanes 1..62) plus one column of
+// each neighbour strip (lanes 0, 63), and `seg_h` rows plus the 2r+2 rows it needs to get going.  Neighbours outside the image
+// take the pixel's own value: that is what the reference's clamped reads return, and `own > own` is false.
+constexpr int WK_COLS = 62;
 
-// NE: region elements per thread held in registers so that ALL global loads are in flight before the first LDS store
-// (a plain load->store loop with run-time bounds is not unrolled and pays one memory round trip per iteration); NE = 0
-// selects that plain loop for very large radii.
-// RT: the circle radius as a compile-time constant (0 = run-time radius).  The kernel is VALU-bound on index arithmetic
-// (measured: SQ_ACTIVE_INST_VALU == kernel time); with RT fixed every tap offset, the region pitch and the divisions by it
-// fold into immediates.
-template<int NE, int RT>
+template<int RT, bool BCOUT>
+__global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
+		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int seg_h, int strips_x, int segs_y, unsigned n_items, int cap, float thr) {
+	constexpr int R = RT, PF = 4, WL = ((2 * R + 1 + PF - 1) / PF) * PF;
+	const int lane = threadIdx.x & 63;
+	// XCD-aware: each XCD walks a contiguous run of work items (strips of one segment row are neighbours), so the 2r+2 columns
+	// adjacent strips share are L2 hits.  Speed only.
+	const unsigned item = __builtin_amdgcn_readfirstlane(vp_xcd_remap(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6));
+	if(item >= n_items) return; // the whole wavefront
+	const int strip = (int)(item % (unsigned)strips_x), t1 = (int)(item / (unsigned)strips_x), seg = t1 % segs_y, z = t1 / segs_y;
+	const int ya = seg * seg_h, yb = min(h, ya + seg_h);
+	const int x = strip * WK_COLS - 1 + lane, xc = vp_clampi(x, 0, w - 1);
+	const uint32_t oa = 4u * (uint32_t)min(xc + R, w - 1), ob = 4u * (uint32_t)min(xc + 1, w - 1), oc = 4u * (uint32_t)max(xc - 1, 0), od = 4u * (uint32_t)max(xc - R, 0);
+	const size_t n = (size_t)w * h;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sat_all + z * n), 0, (int)(n * 4), 0x00020000); // host: n * 4 < 2^31
+	const uint32_t row_bytes = (uint32_t)w * 4u;
+	const bool col_ok = lane >= 1 && lane <= WK_COLS && x < w;
+	const bool x_first = x == 0, x_last = x == w - 1;
+	const float div = (float)(R * R), rcp = 1.0f / div;
+	auto quot = [&](float m) {
+		if(R >= 3 && R <= 10) {
+			// m / (r*r), correctly rounded, without the division sequence: q0 = m*rcp, e = fma(-d, q0, m), q = fma(e, rcp, q0).  Exhaustively
+			// verified equal to m / d for every float m = (float)n, |n| <= 2^27, d = 9 .. 100 (tools/divcheck.hip); box sums are < 2^25.
+			const float q0 = m * rcp;
+			return __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
+		}
+		return m / div;
+	};
+	// Windows of the last WL >= 2r+1 rows of D1 / D2, and the raw SAT values of the next PF rows in flight: a row's four loads are
+	// issued PF steps before they are used (a walk is one dependent chain per lane; without the run-ahead every step would wait a full
+	// memory round trip).  WL is a multiple of PF and the loop is unrolled WL-fold, so every array index below is a constant.
+	int D1[WL], D2[WL], Pa[PF], Pb[PF], Pc[PF], Pd[PF];
+#pragma unroll
+	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
+	float up = 0.f, mid = 0.f; // blobCenter of rows t-2, t-1 while row t is being formed
+	int rej = 0;
+	uint32_t* cand_frame = cand + (size_t)z * cap;
+	const int s0 = ya - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ya - 1 at k = 2r, when the windows are full
+	const int nsteps = 2 * R + (yb - ya) + 2;
+#define VP_WK_ISSUE(SLOT, K)                                                                                                           \
+	do {                                                                                                                               \
+		const uint32_t soff_ = (uint32_t)vp_clampi(s0 + (K) + R, 0, h - 1) * row_bytes; /* SAT row t + r, clamp-to-edge (satBlobCenter.cl:20) */ \
+		Pa[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oa, soff_, 0);                                                             \
+		Pb[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, ob, soff_, 0);                                                             \
+		Pc[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oc, soff_, 0);                                                             \
+		Pd[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, od, soff_, 0);                                                             \
+	} while(0)
+#pragma unroll
+	for(int p = 0; p < PF; p++) VP_WK_ISSUE(p, p);
+	for(int kb = 0; kb < nsteps; kb += WL) {
+#pragma unroll
+		for(int j = 0; j < WL; j++) {
+			const int k = kb + j;
+			D1[j] = (int)((uint32_t)Pa[j % PF] - (uint32_t)Pb[j % PF]);
+			D2[j] = (int)((uint32_t)Pc[j % PF] - (uint32_t)Pd[j % PF]);
+			VP_WK_ISSUE(j % PF, k + PF);
+			const int jp1 = (j - R + 1 + 2 * WL) % WL, jm1 = (j - R - 1 + 2 * WL) % WL, jmr = (j - 2 * R + 2 * WL) % WL; // rows t+1, t-1, t-r (row t+r is j)
+			const int pp = (int)((uint32_t)D1[j] - (uint32_t)D1[jp1]), pn = (int)((uint32_t)D1[jmr] - (uint32_t)D1[jm1]);
+			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
+			const float dn = quot((float)min(min(pp, nn), min(pn, np))); // blobCenter(x, t), t = s0 + k
+			const int t = s0 + k;
+			if(BCOUT && k >= 2 * R && t >= ya && t < yb && col_ok) bc_out[z * n + (size_t)t * w + x] = dn;
+			const int y = t - 1; // the row whose four neighbours are now known
+			if(k >= 2 * R + 2 && y < yb) { // scalar condition
+				const float v = mid;
+				float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); // wave_shr:1: lane i <- lane i-1
+				float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); // wave_shl:1: lane i <- lane i+1
+				if(x_first) lf = v;
+				if(x_last) rt = v;
+				const float uv = y == 0 ? v : up, dv = y == h - 1 ? v : dn;
+				const bool above = col_ok && !(v < thr);                                   // blobList.cl:39
+				const bool peak = !(lf > v || rt > v || uv > v || dv > v);                 // :47-52, strict '>'
+				rej += __popcll(__ballot(above && !peak));                                 // :53 counter[2]++
+				wave_append(above && peak, (uint32_t)(y * w + x), cand_frame, cand_count + z, cap, lane);
+			}
+			up = mid;
+			mid = dn;
+		}
+	}
+#undef VP_WK_ISSUE
+	if(rej != 0 && lane == 0) atomicAdd(&counter[3 * z + 2], rej);
+}
+
+// Run-time radius fallback (radii outside the specialised range): the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge
+// addressing (satBlobCenter.cl:20, H7), the box-sum image Bx and then blobCenter for the 64x64 tile plus a 1-pixel ring are built in
+// LDS, then thresholded / peak-tested.  Out-of-image ring positions take the value of the clamped position.
+constexpr int FT_W = 64, FT_H = 64, FT_NT = 512;
+
 __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
-		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r_arg, float thr) {
+		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int r, float thr, int cap) {
 	extern __shared__ __attribute__((aligned(16))) char smem_tail[];
-	const int r = RT > 0 ? RT : r_arg;
 	const int halo = r + 1;
-	// horizontal halo rounded up to whole 16-byte groups when the radius is a compile-time constant: interior tiles are then
-	// fetched with aligned dwordx4 loads and no clamping (the two paths fill the same LDS layout)
-	const int HA = RT > 0 ? ((RT + 1 + 3) & ~3) : halo, XO = HA - halo;
-	const int RW = FT_W + 2 * HA, RH = FT_H + 2 * halo;
-	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - HA + rx)]
-	// 1-D grid, XCD-aware: each XCD walks a contiguous run of tiles (row-major inside a frame), so the halo lines neighbouring
-	// tiles share are L2 hits instead of one HBM fetch per XCD
+	const int RW = FT_W + 2 * halo, RH = FT_H + 2 * halo;
+	uint32_t* region = reinterpret_cast<uint32_t*>(smem_tail); // region[ry][rx] = SAT[clamp(y0 - halo + ry)][clamp(x0 - halo + rx)]
 	const unsigned tiles_x = (unsigned)(w + FT_W - 1) / FT_W, tiles_y = (unsigned)(h + FT_H - 1) / FT_H;
 	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
 	const int z = (int)(lb / (tiles_x * tiles_y));
@@ -254,199 +413,107 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 	const int32_t* sat = sat_all + z * n;
 	const int x0 = (int)(trem % tiles_x) * FT_W, y0 = (int)(trem / tiles_x) * FT_H;
 	const int tid = threadIdx.x;
-	const bool vec_ok = RT > 0 && (w & 3) == 0 && w >= 4 && (reinterpret_cast<uintptr_t>(sat_all) & 15) == 0;
-	const bool interior = vec_ok && x0 - HA >= 0 && x0 + FT_W + HA <= w && y0 - halo >= 0 && y0 + FT_H + halo <= h;
-	if(vec_ok) { // workgroup-uniform.  Border tiles too: rows clamp by index; a 4-pixel group is either wholly inside the image or wholly
-	             // outside it (w, x0 and HA are multiples of 4), and an outside group is the edge column replicated (clamp-to-edge)
-		constexpr int RW4 = RT > 0 ? (FT_W + 2 * ((RT + 1 + 3) & ~3)) / 4 : 1, RHc = RT > 0 ? FT_H + 2 * (RT + 1) : 1, NV = (RW4 * RHc + FT_NT - 1) / FT_NT;
-		int4 v4[NV];
-#pragma unroll
-		for(int k = 0; k < NV; k++) {
-			const int i = min(tid + FT_NT * k, RW4 * RHc - 1), row = i / RW4, c4 = i - row * RW4;
-			const int gy = interior ? y0 - halo + row : vp_clampi(y0 - halo + row, 0, h - 1), gx = x0 - HA + 4 * c4;
-			typedef int v4i_ __attribute__((ext_vector_type(4)));
-			const v4i_ vv = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sat + (size_t)gy * w + (interior ? gx : vp_clampi(gx, 0, w - 4))));
-			const int4 v = make_int4(vv.x, vv.y, vv.z, vv.w);
-			v4[k] = interior || (gx >= 0 && gx < w) ? v : (gx < 0 ? make_int4(v.x, v.x, v.x, v.x) : make_int4(v.w, v.w, v.w, v.w));
-		}
-#pragma unroll
-		for(int k = 0; k < NV; k++)
-			if(tid + FT_NT * k < RW4 * RHc) reinterpret_cast<int4*>(region)[tid + FT_NT * k] = v4[k];
-	} else if(NE > 0) {
-		uint32_t v[NE > 0 ? NE : 1];
-		const int total = RW * RH, dq = FT_NT / RW, dr = FT_NT - dq * RW;
-		int ry = tid / RW, rx = tid - ry * RW;
-#pragma unroll
-		for(int k = 0; k < NE; k++) {
-			v[k] = (k * FT_NT + tid < total) ? (uint32_t)sat[(size_t)vp_clampi(y0 - halo + ry, 0, h - 1) * w + vp_clampi(x0 - HA + rx, 0, w - 1)] : 0u;
-			ry += dq;
-			rx += dr;
-			if(rx >= RW) {
-				rx -= RW;
-				ry++;
-			}
-		}
-#pragma unroll
-		for(int k = 0; k < NE; k++)
-			if(k * FT_NT + tid < total) region[k * FT_NT + tid] = v[k];
-	} else {
-		for(int ry = tid >> 6; ry < RH; ry += FT_NT / 64) {
-			const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
-			for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - HA + rx, 0, w - 1)];
-		}
+	for(int ry = tid >> 6; ry < RH; ry += FT_NT / 64) {
+		const int gy = vp_clampi(y0 - halo + ry, 0, h - 1);
+		for(int rx = tid & 63; rx < RW; rx += 64) region[ry * RW + rx] = (uint32_t)sat[(size_t)gy * w + vp_clampi(x0 - halo + rx, 0, w - 1)];
 	}
 	__syncthreads();
-	// All four quadrant sums of satBlobCenter.cl:37-40 are ONE box-sum image sampled at four offsets:
-	//   Bx(u, v) = S(u+r-1, v+r-1) - S(u+r-1, v) - S(u, v+r-1) + S(u, v)        (every tap clamped on its own, as in the reference)
-	//   pp(x, y) = Bx(x+1, y+1),  nn = Bx(x-r, y-r),  pn = -Bx(x+1, y-r),  np = -Bx(x-r, y+1)
-	// so Bx is built once (4 LDS taps per entry) and blobCenter needs 4 reads instead of 16.  Bx covers u in
-	// [x0-1-r, x0+FT_W+1], v likewise (its origin coincides with the region's); wrapping int32 arithmetic, exact.
+	// Bx covers u in [x0-1-r, x0+FT_W+1], v likewise (its origin coincides with the region's); wrapping int32 arithmetic, exact
 	const int BXW = FT_W + r + 3, BXH = FT_H + r + 3;
 	int32_t* bx = reinterpret_cast<int32_t*>(region + RW * RH);
-	// A wavefront that straddled two rows of the 72-wide image would touch a span of more than 64 dwords: 2-way bank conflicts on
-	// every tap (measured: SQ_LDS_BANK_CONFLICT = 54 % of the LDS cycles).  So: columns 0..63 with one row per wavefront, then the
-	// few remaining columns.
-	auto bx_entry = [&](int by, int bxx) {
-		const uint32_t* c = region + by * RW + bxx + XO;
-		bx[by * BXW + bxx] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
-	};
-	// Odd compile-time radius, interior tile: two horizontally adjacent entries per thread through 8-byte LDS accesses (ds_read_b64 /
-	// ds_write_b64 move 256 B per clock, the 4-byte forms 128 B).  With r odd every tap of an even-column pair is 8-byte aligned:
-	// RW, BXW, BW and XO are even and the blobCenter taps sit at odd offsets (+1, -r) from an odd column (bxx + r).
-	constexpr bool PAIRS = RT > 0 && (RT & 1) == 1;
-	const bool pairs = PAIRS && interior; // workgroup-uniform; blobCenter clamps its centre on border tiles, the box sums never clamp
-	if(PAIRS && vec_ok) {
-		auto bx_pair = [&](int by, int bxx) {
-			const uint32_t* c = region + by * RW + bxx + XO;
-			const uint2 t11 = *reinterpret_cast<const uint2*>(c + (r - 1) * RW + (r - 1)), t10 = *reinterpret_cast<const uint2*>(c + (r - 1));
-			const uint2 t01 = *reinterpret_cast<const uint2*>(c + (r - 1) * RW), t00 = *reinterpret_cast<const uint2*>(c);
-			*reinterpret_cast<int2*>(bx + by * BXW + bxx) = make_int2((int32_t)(t11.x - t10.x - t01.x + t00.x), (int32_t)(t11.y - t10.y - t01.y + t00.y));
-		};
-		for(int e = tid; e < 32 * BXH; e += FT_NT) bx_pair(e >> 5, 2 * (e & 31)); // one row per 32-lane half (the bank-conflict group of b64)
-		const int xp = (BXW - 64) / 2;
-		for(int e = tid; e < xp * BXH; e += FT_NT) {
-			const int by = e / xp;
-			bx_pair(by, 64 + 2 * (e - by * xp));
-		}
-	} else {
-		for(int e = tid; e < 64 * BXH; e += FT_NT) bx_entry(e >> 6, e & 63);
-		const int extra = BXW - 64; // r + 3 columns
-		for(int e = tid; e < extra * BXH; e += FT_NT) {
-			const int by = e / extra;
-			bx_entry(by, 64 + (e - by * extra));
-		}
+	for(int e = tid; e < BXW * BXH; e += FT_NT) {
+		const int by = e / BXW, bxx = e - by * BXW;
+		const uint32_t* c = region + by * RW + bxx;
+		bx[e] = (int32_t)(c[(r - 1) * RW + (r - 1)] - c[r - 1] - c[(r - 1) * RW] + c[0]);
 	}
 	__syncthreads();
-	const float div = (float)(r * r), rcp = 1.0f / div;
+	const float div = (float)(r * r);
 	constexpr int BW = FT_W + 2, BH = FT_H + 2;
 	float* bc = reinterpret_cast<float*>(region); // the blobCenter ring tile aliases the (now dead) SAT region
-	auto bc_entry = [&](int by, int bxx) {
-		const int e = by * BW + bxx;
+	for(int e = tid; e < BW * BH; e += FT_NT) {
+		const int by = e / BW, bxx = e - by * BW;
 		// clamped centre, in Bx coordinates (origin x0-1-r, y0-1-r)
 		const int cx = vp_clampi(x0 - 1 + bxx, 0, w - 1) - (x0 - 1 - r), cy = vp_clampi(y0 - 1 + by, 0, h - 1) - (y0 - 1 - r);
 		const int32_t* c = bx + cy * BXW + cx;
-		// min(min(pp, nn), min(pn, np)) of satBlobCenter.cl:41 taken on the exact int32 box sums and converted once: int -> float
-		// conversion is monotonic, so the converted minimum equals the minimum of the converted values
-		const float m = (float)min(min(c[BXW + 1], c[-r * BXW - r]), min(-c[-r * BXW + 1], -c[BXW - r]));
-		if(RT >= 3 && RT <= 10) {
-			// m / (r*r), correctly rounded, without the division sequence: q0 = m*rcp, e = fma(-d, q0, m), q = fma(e, rcp, q0).
-			// Exhaustively verified equal to m / d for every float m = (float)n, |n| <= 2^27, d = 9 .. 100 (tools/divcheck.hip);
-			// the box sums here are bounded by 100 * 3 * 255^2 < 2^25.
-			const float q0 = m * rcp;
-			bc[e] = __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
-		} else bc[e] = m / div;
-	};
-	if(pairs) { // interior: no clamping, cx = bxx + r, cy = by + r
-		auto quot = [&](float m) {
-			const float q0 = m * rcp;
-			return __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0); // PAIRS implies 3 <= RT <= 9: see bc_entry
-		};
-		auto bc_pair = [&](int by, int bxx) {
-			const int32_t* c = bx + (by + r) * BXW + bxx + r;
-			const int2 ppi = *reinterpret_cast<const int2*>(c + BXW + 1), nni = *reinterpret_cast<const int2*>(c - r * BXW - r);
-			const int2 pni = *reinterpret_cast<const int2*>(c - r * BXW + 1), npi = *reinterpret_cast<const int2*>(c + BXW - r);
-			float2 o;
-			o.x = quot((float)min(min(ppi.x, nni.x), min(-pni.x, -npi.x))); // integer minimum, one conversion (see bc_entry)
-			o.y = quot((float)min(min(ppi.y, nni.y), min(-pni.y, -npi.y)));
-			*reinterpret_cast<float2*>(bc + by * BW + bxx) = o;
-		};
-		static_assert(!PAIRS || (RT >= 3 && RT <= 10), "the fma quotient is verified for r = 3 .. 10 only");
-		for(int e = tid; e < 32 * BH; e += FT_NT) bc_pair(e >> 5, 2 * (e & 31));
-		for(int e = tid; e < BH; e += FT_NT) bc_pair(e, 64); // the ring columns 64, 65
-	} else {
-		for(int e = tid; e < 64 * BH; e += FT_NT) bc_entry(e >> 6, e & 63); // one row per wavefront (see above), then the two ring columns
-		for(int e = tid; e < 2 * BH; e += FT_NT) bc_entry(e >> 1, 64 + (e & 1));
+		bc[e] = (float)min(min(c[BXW + 1], c[-r * BXW - r]), min(-c[-r * BXW + 1], -c[BXW - r])) / div;
 	}
 	__syncthreads();
-	for(int e = tid; e < FT_W * FT_H; e += FT_NT) {
+	int rej = 0;
+	for(int e = tid; e < FT_W * FT_H; e += FT_NT) { // one tile row per wavefront step: every lane of a wavefront takes part
 		const int ty = e / FT_W, tx = e - ty * FT_W;
 		const int x = x0 + tx, y = y0 + ty;
-		if(x >= w || y >= h) continue;
+		const bool in = x < w && y < h;
 		const float* p = bc + (ty + 1) * BW + tx + 1;
 		const float v = p[0];
-		if(bc_out) bc_out[z * n + (size_t)y * w + x] = v;
-		if(v < thr) continue;
-		if(p[-1] > v || p[1] > v || p[-BW] > v || p[BW] > v) {
-			atomicAdd(&counter[3 * z + 2], 1);
-			continue;
-		}
-		const int slot = atomicAdd(&cand_count[z], 1);
-		cand[z * n + slot] = (uint32_t)(y * w + x);
+		if(bc_out && in) bc_out[z * n + (size_t)y * w + x] = v;
+		const bool above = in && !(v < thr);
+		const bool peak = !(p[-1] > v || p[1] > v || p[-BW] > v || p[BW] > v);
+		rej += __popcll(__ballot(above && !peak));
+		wave_append(above && peak, (uint32_t)(y * w + x), cand + (size_t)z * cap, cand_count + z, cap, tid & 63);
 	}
+	if(rej != 0 && (tid & 63) == 0) atomicAdd(&counter[3 * z + 2], rej);
 }
 
 // blobcenter != nullptr: list from a materialised blobCenter image (vp_bloblist).  Otherwise fused from the SAT
-// (vp_blobcenter_list): blobCenter lives in LDS only, `bc_out` (optional) receives the debug view.
-static int list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
-		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, const ListScratch& ws) {
+// (vp_blobcenter_list): blobCenter stays in registers, `bc_out` (optional) receives the debug view.
+// counters_zeroed: the caller's counter[3 x batch] was already cleared on this stream (vp_frame lets the SAT kernel do it).
+int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
+		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed) {
 	hipStream_t s = ctx->streams[stream];
-	// main.cpp:283-288: the host zeroes counter[3] before every launch; here one small kernel clears it and the candidate counters
-	// (two hipMemsetAsync calls cost ~10 us each)
-	k_zero2<<<vp_div_up(3 * batch, 256), 256, 0, s>>>(counter, 3 * batch, ws.cand_count, batch);
-	VP_TRY(vp_launch_ok("blobList counters"));
-	uint32_t* idx_work = (order == VP_ORDER_RASTER || !idx) ? ws.idx : idx;
-	// RASTER order: the emit kernels append into workspace records, k_rank_scatter sorts them straight into the caller's arrays
-	uint8_t* rec_work = order == VP_ORDER_RASTER ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
+	ListScratch ws;
+	VP_TRY(list_scratch(ctx, stream, batch, max_matches, &ws));
+	if(!counters_zeroed) { // main.cpp:283-288: the host zeroes counter[3] before every launch
+		k_zero<<<vp_div_up(3 * batch, 256), 256, 0, s>>>(counter, 3 * batch);
+		VP_TRY(vp_launch_ok("blobList counters"));
+	}
+	const bool raster = order == VP_ORDER_RASTER;
+	uint32_t* idx_work = (raster || !idx) ? ws.idx : idx;
+	// RASTER order: the emit kernel appends into workspace records and its last workgroup per frame sorts them into the caller's arrays
+	uint8_t* rec_work = raster ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
 	if(blobcenter) {
-		k_detect<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, s>>>(blobcenter, ws.cand, ws.cand_count, counter, w, h, thr);
+		k_detect<<<dim3(vp_div_up(w, 64), vp_div_up(h, 4), batch), dim3(64, 4), 0, s>>>(blobcenter, ws.cand, ws.cand_count, counter, w, h, thr, ws.cap);
 		VP_TRY(vp_launch_ok("blobList detect"));
-		k_emit<false><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, counter, rec_work, idx_work,
-				w, h, min_score, radius, max_matches, 0);
+		k_emit<false><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), blobcenter, ws.cand, ws.cand_count, ws.done, counter, rec_work, idx_work,
+				w, h, thr, min_score, radius, max_matches, 0, ws.cap, order, reinterpret_cast<uint8_t*>(matches), idx);
+		return vp_launch_ok("blobList emit");
+	}
+	if(circle_radius >= 2 && circle_radius <= 12 && (size_t)w * h * 4 < 0x7fffffffu) {
+		const int strips_x = (int)vp_div_up(w, WK_COLS);
+		// rows per wavefront: long walks amortise the 2r+2 start-up rows, short ones give a small launch enough wavefronts
+		int seg_h = ctx->tune.tail_segment_rows;
+		if(seg_h <= 0) {
+			seg_h = 16;
+			for(int cand_h : {128, 64, 32})
+				if((long long)strips_x * vp_div_up(h, cand_h) * batch >= 8192) {
+					seg_h = cand_h;
+					break;
+				}
+		}
+		const int segs_y = (int)vp_div_up(h, seg_h);
+		const long long items = (long long)strips_x * segs_y * batch;
+		VP_REQUIRE(items < (1ll << 31), "vp_blobcenter_list: too many work items");
+		const unsigned grid = (unsigned)((items + 3) / 4);
+#define VP_WK(R) \
+		case R: \
+			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, seg_h, strips_x, segs_y, (unsigned)items, ws.cap, thr); \
+			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, seg_h, strips_x, segs_y, (unsigned)items, ws.cap, thr); \
+			break
+		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale))
+			VP_WK(2); VP_WK(3); VP_WK(4); VP_WK(5); VP_WK(6); VP_WK(7); VP_WK(8); VP_WK(9); VP_WK(10); VP_WK(11); VP_WK(12);
+		}
+#undef VP_WK
 	} else {
 		const int halo = circle_radius + 1;
-		const int ha = (circle_radius >= 3 && circle_radius <= 10) ? ((halo + 3) & ~3) : halo; // k_circle_detect: aligned horizontal halo of the specialised radii
-		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * ha) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
+		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
 		VP_REQUIRE(lds <= 160 * 1024, "vp_blobcenter_list: circle radius %d too large for the LDS tile", circle_radius);
-		const int per_thread = ((FT_W + 2 * halo) * (FT_H + 2 * halo) + FT_NT - 1) / FT_NT;
 		VP_REQUIRE((long long)vp_div_up(w, FT_W) * vp_div_up(h, FT_H) * batch < (1ll << 31), "vp_blobcenter_list: too many tiles");
-		const dim3 grid((unsigned)(vp_div_up(w, FT_W) * vp_div_up(h, FT_H) * batch));
-#define VP_CD(N, R) \
-		do { \
-			if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect<N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-			k_circle_detect<N, R><<<grid, FT_NT, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr); \
-		} while(0)
-#define VP_CD_R(R) case R: VP_CD(((FT_W + 2 * ((R + 1 + 3) & ~3)) * (FT_H + 2 * (R + 1)) + FT_NT - 1) / FT_NT, R); break
-		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale)): compile-time specialisations
-			VP_CD_R(3); VP_CD_R(4); VP_CD_R(5); VP_CD_R(6); VP_CD_R(7); VP_CD_R(8); VP_CD_R(9); VP_CD_R(10);
-		default:
-			if(per_thread <= 14) VP_CD(14, 0);
-			else if(per_thread <= 20) VP_CD(20, 0);
-			else if(per_thread <= 32) VP_CD(32, 0);
-			else VP_CD(0, 0);
-		}
-#undef VP_CD_R
-#undef VP_CD
-		VP_TRY(vp_launch_ok("circle+detect"));
-		k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, counter, rec_work, idx_work,
-				w, h, min_score, radius, max_matches, circle_radius);
+		if(lds > 48 * 1024) VP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circle_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		k_circle_detect<<<dim3((unsigned)(vp_div_up(w, FT_W) * vp_div_up(h, FT_H) * batch)), FT_NT, lds, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, circle_radius, thr, ws.cap);
 	}
-	VP_TRY(vp_launch_ok("blobList emit"));
-	if(order == VP_ORDER_RASTER) {
-		const dim3 grid(vp_div_up(max_matches, 256), batch);
-		k_rank_scatter<<<grid, 256, 0, s>>>(ws.rec_tmp, ws.idx, counter, reinterpret_cast<uint8_t*>(matches), idx, max_matches);
-		VP_TRY(vp_launch_ok("blobList rank"));
-	}
-	return VP_OK;
+	VP_TRY(vp_launch_ok("circle+detect"));
+	k_emit<true><<<dim3(64, batch), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(flat), sat, ws.cand, ws.cand_count, ws.done, counter, rec_work, idx_work,
+			w, h, thr, min_score, radius, max_matches, circle_radius, ws.cap, order, reinterpret_cast<uint8_t*>(matches), idx);
+	return vp_launch_ok("blobList emit");
 }
 
 static int list_args_ok(const char* name, const void* flat, const void* src, int w, int h, int batch, int radius, int max_matches, int order, const void* matches, const void* counter) {
@@ -463,10 +530,8 @@ extern "C" int vp_bloblist(VpContext* ctx, int stream, const uint8_t* flat, cons
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_TRY(list_args_ok("vp_bloblist", flat, blobcenter, w, h, batch, radius, max_matches, order, matches, counter));
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
-	ListScratch ws;
-	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, false, &ws));
 	VpStageTimer t(ctx, stream, "blobList");
-	return list_from_blobcenter(ctx, stream, flat, blobcenter, nullptr, 0, nullptr, w, h, batch, circ_threshold, min_score, radius, max_matches, order, matches, idx, counter, ws);
+	return vp_list_from_blobcenter(ctx, stream, flat, blobcenter, nullptr, 0, nullptr, w, h, batch, circ_threshold, min_score, radius, max_matches, order, matches, idx, counter, false);
 }
 
 extern "C" int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* flat, const int32_t* sat, int w, int h, int batch,
@@ -476,10 +541,8 @@ extern "C" int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* fla
 	VP_TRY(list_args_ok("vp_blobcenter_list", flat, sat, w, h, batch, list_radius, max_matches, order, matches, counter));
 	VP_REQUIRE(circle_radius >= 0, "vp_blobcenter_list: bad circle radius");
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
-	ListScratch ws;
-	VP_TRY(list_scratch(ctx, stream, (size_t)w * h, batch, max_matches, false, &ws));
 	VpStageTimer t(ctx, stream, "satBlobCenter+blobList");
-	return list_from_blobcenter(ctx, stream, flat, nullptr, sat, circle_radius, blobcenter_out, w, h, batch, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter, ws);
+	return vp_list_from_blobcenter(ctx, stream, flat, nullptr, sat, circle_radius, blobcenter_out, w, h, batch, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter, false);
 }
 
 // ---------------------------------------------------------------- validation kernels -------------------------------

@@ -4,6 +4,7 @@
 // This is the loop of src/main.cpp:262-372 for many cameras at once: what a deployment that puts several cameras on one MI355X runs.
 //
 // usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1]
+//        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--verify]     (feeds_multi.cpp: N devices, RCCL gather of the records)
 // Scene and geometry: SURVEY.md 8(d) cfg2 (2048x1536 RGGB, nadir camera 5 m over a 9.6 x 7.2 m patch, 16 robots, 8 balls per feed).
 #include <chrono>
 #include <cmath>
@@ -24,38 +25,60 @@
 		} \
 	} while(0)
 
+int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify); // feeds_multi.cpp
+
+// cfg2: kernel scalars assigned directly
+void vp_feeds_cfg2_params(VpFrameParams* out) {
+	const int qw = 1024, qh = 768;
+	const float fieldScale = 4.6875f;
+	VpFrameParams p;
+	memset(&p, 0, sizeof(p));
+	p.layout = VP_LAYOUT_RGGB;
+	p.qw = qw;
+	p.qh = qh;
+	vp_synth_camera(qw, qh, 5000.f, 180.f, 9600.f, 0.08f, &p.model);
+	p.max_robot_height = 180.f;
+	p.field_scale = fieldScale;
+	p.off_x = -4800.f;
+	p.off_y = -3600.f;
+	p.fw = 2048;
+	p.fh = 1536;
+	p.grad_offset = (int)ceilf(25.0f / fieldScale) / 3; // Resources.cpp:160
+	p.circle_radius = (int)ceilf(20.0f / fieldScale);  // :163
+	p.list_radius = (int)floorf(20.0f / fieldScale);   // main.cpp:289
+	p.circ_threshold = 15.0f;
+	p.min_score = 0.0f;
+	p.max_matches = 2000;
+	p.sampler_mode = VP_SAMPLER_BILINEAR_RTZ;
+	p.sat_variant = VP_SAT_TILED;
+	p.order = VP_ORDER_RASTER;
+	p.use_coord_map = 1;
+	*out = p;
+}
+
 int main(int argc, char** argv) {
+	if(argc > 2 && strcmp(argv[1], "--gpus") == 0) {
+		int verify = 0, pos[3] = {128, 20, 3}, np = 0;
+		for(int i = 3; i < argc; i++) {
+			if(strcmp(argv[i], "--verify") == 0) verify = 1;
+			else if(np < 3) pos[np++] = atoi(argv[i]);
+		}
+		if(pos[0] < 1 || pos[1] < 1 || pos[2] < 0) {
+			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--verify]\n");
+			return 2;
+		}
+		return vp_feeds_run_multi(atoi(argv[2]), pos[0], pos[1], pos[2], verify);
+	}
 	const int feeds = argc > 1 ? atoi(argv[1]) : 128, steps = argc > 2 ? atoi(argv[2]) : 20, warmup = argc > 3 ? atoi(argv[3]) : 3;
 	const int threads = argc > 4 ? atoi(argv[4]) : 16, detect = argc > 5 ? atoi(argv[5]) : 1;
 	if(feeds < 1 || steps < 1 || warmup < 0 || threads < 1) {
 		fprintf(stderr, "usage: vp_feeds [feeds] [steps] [warmup] [host_threads] [detect 0|1]\n");
 		return 2;
 	}
-	// cfg2: kernel scalars assigned directly
-	const int qw = 1024, qh = 768, fw = 2048, fh = 1536, maxBlobs = 2000, robots = 16, balls = 8;
-	const float fieldScale = 4.6875f, offX = -4800.f, offY = -3600.f, planeHeight = 180.f, fieldLen = 9000.f, fieldWid = 6000.f;
 	VpFrameParams p;
-	memset(&p, 0, sizeof(p));
-	p.layout = VP_LAYOUT_RGGB;
-	p.qw = qw;
-	p.qh = qh;
-	vp_synth_camera(qw, qh, 5000.f, planeHeight, 9600.f, 0.08f, &p.model);
-	p.max_robot_height = planeHeight;
-	p.field_scale = fieldScale;
-	p.off_x = offX;
-	p.off_y = offY;
-	p.fw = fw;
-	p.fh = fh;
-	p.grad_offset = (int)ceilf(25.0f / fieldScale) / 3; // Resources.cpp:160
-	p.circle_radius = (int)ceilf(20.0f / fieldScale);  // :163
-	p.list_radius = (int)floorf(20.0f / fieldScale);   // main.cpp:289
-	p.circ_threshold = 15.0f;
-	p.min_score = 0.0f;
-	p.max_matches = maxBlobs;
-	p.sampler_mode = VP_SAMPLER_BILINEAR_RTZ;
-	p.sat_variant = VP_SAT_TILED;
-	p.order = VP_ORDER_RASTER;
-	p.use_coord_map = 1;
+	vp_feeds_cfg2_params(&p);
+	const int qw = p.qw, qh = p.qh, fw = p.fw, fh = p.fh, maxBlobs = p.max_matches, robots = 16, balls = 8;
+	const float fieldScale = p.field_scale, offX = p.off_x, offY = p.off_y, planeHeight = p.max_robot_height, fieldLen = 9000.f, fieldWid = 6000.f;
 
 	VpContext* ctx = nullptr;
 	CK(vp_ctx_create(0, 2, &ctx));
