@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -32,7 +33,7 @@ def test_header_declares_the_hot_path():
 
 
 def test_libraries_export_every_declared_symbol(built):
-    hip = C.CDLL(os.path.join(PKG, "libvp_hip.so"))
+    hip = cases.vp.load_capi().lib()  # imports torch first: one HIP runtime per process (the copy PyTorch bundles)
     host = C.CDLL(os.path.join(PKG, "libvp_host.so"))
     missing = [f for f in declared_functions() if not (hasattr(hip, f) or hasattr(host, f))]
     assert not missing, missing
@@ -44,24 +45,62 @@ def test_libraries_export_every_declared_symbol(built):
 
 def test_multi_gpu_library_exports_the_gather(built):
     """include/vp_multi.h (one process, N devices, RCCL all-gather of the per-step records) lives in libvp_multi.so; libvp_hip.so
-    itself stays free of the RCCL dependency.  Without a GPU the constructor fails loudly."""
-    import torch  # noqa: F401  (one HIP runtime per process: the copy bundled with PyTorch, as capi.lib() does)
-    C.CDLL(os.path.join(PKG, "libvp_hip.so"), mode=C.RTLD_GLOBAL)
-    multi = C.CDLL(os.path.join(PKG, "libvp_multi.so"))
+    itself stays free of the RCCL dependency.  Without a GPU the constructor fails loudly.  (Loaded in a child process: RCCL brings the
+    system HIP runtime, which must not meet the copy PyTorch bundles in the test process.)"""
     fns = declared_functions("vp_multi.h", "vp_")
     assert {"vp_gather_create", "vp_gather_start", "vp_gather_wait", "vp_gather_send", "vp_gather_recv", "vp_record_layout", "vp_gather_destroy"} <= set(fns)
-    missing = [f for f in fns if not hasattr(multi, f)]
-    assert not missing, missing
     assert "rccl" in subprocess.run(["ldd", os.path.join(PKG, "libvp_multi.so")], capture_output=True, text=True).stdout
     assert "rccl" not in subprocess.run(["ldd", os.path.join(PKG, "libvp_hip.so")], capture_output=True, text=True).stdout
-    multi.vp_record_layout.restype = C.c_size_t
-    oc, om, oi = C.c_size_t(), C.c_size_t(), C.c_size_t()
-    total = multi.vp_record_layout(3, 2000, C.byref(oc), C.byref(om), C.byref(oi))
-    assert oc.value == 0 and om.value == 256 and oi.value == 256 + 132096 and total == oi.value + 24064 and total % 256 == 0
+    code = f"""
+import ctypes as C, os, json
+C.CDLL(os.path.join({PKG!r}, "libvp_hip.so"), mode=C.RTLD_GLOBAL)
+multi = C.CDLL(os.path.join({PKG!r}, "libvp_multi.so"))
+missing = [f for f in {fns!r} if not hasattr(multi, f)]
+multi.vp_record_layout.restype = C.c_size_t
+oc, om, oi = C.c_size_t(), C.c_size_t(), C.c_size_t()
+total = multi.vp_record_layout(3, 2000, C.byref(oc), C.byref(om), C.byref(oi))
+g = C.c_void_p(); dev = (C.c_int * 1)(0)
+rc = multi.vp_gather_create(1, dev, C.c_size_t(total), 2, C.byref(g))
+print(json.dumps(dict(missing=missing, layout=[oc.value, om.value, oi.value, total], rc=rc)))
+"""
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import json
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert not r["missing"], r["missing"]
+    assert r["layout"] == [0, 256, 256 + 132096, 256 + 132096 + 24064]
+    import torch
     if not torch.cuda.is_available():
-        g = C.c_void_p()
-        dev = (C.c_int * 1)(0)
-        assert multi.vp_gather_create(1, dev, C.c_size_t(total), 2, C.byref(g)) == -5  # VP_ERR_NODEVICE
+        assert r["rc"] == -5  # VP_ERR_NODEVICE: no CPU fallback
+
+
+def device_disassembly(so_path, tmp_path):
+    """gfx950 disassembly of every code object bundled in a HIP shared library (one offload bundle per translation unit)."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat = os.path.join(tmp_path, "fat.bin")
+    subprocess.run(["objcopy", "--dump-section", f".hip_fatbin={fat}", so_path, os.path.join(tmp_path, "copy.so")], check=True)  # never without an output file: objcopy would rewrite the library in place
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    out = []
+    for i, a in enumerate(starts):
+        piece = os.path.join(tmp_path, f"bundle{i}.bin")
+        open(piece, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = os.path.join(tmp_path, f"dev{i}.co")
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        out.append(subprocess.run([f"{llvm}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout)
+    return out
+
+
+def test_no_reversed_dpp_subtraction_in_the_device_code(built, tmp_path):
+    """On gfx950 (ROCm 7.2) v_subrev_u32_dpp / v_subrev_f32_dpp shift the wrong operand (a - shl(e) executes as shl(a) - e; shown in
+    isolation by tools/dbg/dpp_test.hip, found as wrong blobCenter values in round 2).  hipcc emits the instruction when a DPP-shifted
+    value is the subtrahend of a subtraction it can fold the shift into; the kernels are written so that this never happens."""
+    texts = device_disassembly(os.path.join(PKG, "libvp_hip.so"), str(tmp_path))
+    assert len(texts) >= 4 and sum(t.count("_dpp") for t in texts) > 50  # the check really sees the kernels' DPP instructions
+    bad = [ln.strip() for t in texts for ln in t.splitlines() if re.search(r"v_subrev\w*_dpp|v_subbrev\w*_dpp", ln)]
+    assert not bad, bad[:5]
 
 
 def test_host_library_exports_the_detection_stage(built):

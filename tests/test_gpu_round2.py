@@ -238,16 +238,18 @@ def test_map_and_unmap_from_other_threads_while_the_main_thread_launches(env, po
         threads = [threading.Thread(target=writer), threading.Thread(target=reader, args=(2,)), threading.Thread(target=reader, args=(3,))]
         for t in threads:
             t.start()
-        p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
-        for it in range(150):
-            ctx.frame(p, d_raw, 1, flat, sat, m, cnt, idx=idx, stream=0)
-            if it % 10 == 9:
-                ctx.sync(0)
-                c = cnt.cpu().numpy()[0]
-                assert np.array_equal(c, want["cnt"])
-        stop.set()
-        for t in threads:
-            t.join(30)
+        try:
+            p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
+            for it in range(150):
+                ctx.frame(p, d_raw, 1, flat, sat, m, cnt, idx=idx, stream=0)
+                if it % 10 == 9:
+                    ctx.sync(0)
+                    c = cnt.cpu().numpy()[0]
+                    assert np.array_equal(c, want["cnt"])
+        finally:  # the helper threads must be gone before the context is
+            stop.set()
+            for t in threads:
+                t.join(30)
         assert not errors, errors
         ctx.sync()
         n = min(int(want["cnt"][0]), mm)

@@ -121,17 +121,27 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ circ, 
 	wave_append(above && peak, (uint32_t)(y * w + x), cand + (size_t)z * cap, cand_count + z, cap, threadIdx.x);
 }
 
+// 22-byte packed record (blobList.cl:26-32): only 2-byte alignment is guaranteed.  The pieces are WRITE-THROUGH stores (agent-scope
+// relaxed, global_store_short sc1): the workgroup that sorts a frame's records reads what other CUs wrote in the same launch, and
+// write-through stores need no release fence (cdna_hip_programming.md Guideline 16, R1) -- a __threadfence() per emitting workgroup
+// (buffer_wbl2: an L2-wide write-back each) made this kernel 20 x slower than the work it does.
+typedef __attribute__((address_space(1))) uint16_t gu16_t;
+typedef __attribute__((address_space(1))) uint32_t gu32_t;
+__device__ __forceinline__ void st_wt16(uint16_t* p, uint32_t v) { __hip_atomic_store((gu16_t*)p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the matching loads (global_load_ushort / dword sc1): they bypass this CU's L1 and are coherent with the write-through stores of
+// other CUs on any XCD -- a plain load could be served a stale copy of the line (the workspace is reused by every launch)
+__device__ __forceinline__ uint16_t ld_wt16(const uint16_t* p) { return __hip_atomic_load((gu16_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_wt32(const uint32_t* p) { return __hip_atomic_load((gu32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_match(uint8_t* dst, float x, float y, const uint32_t color[3], uint32_t center, float circ, float score) {
-	// 22-byte packed record (blobList.cl:26-32): only 2-byte alignment is guaranteed
 	uint16_t* d = reinterpret_cast<uint16_t*>(dst);
 	const uint32_t xb = __float_as_uint(x), yb = __float_as_uint(y), cb = __float_as_uint(circ), sb = __float_as_uint(score);
-	d[0] = (uint16_t)xb; d[1] = (uint16_t)(xb >> 16);
-	d[2] = (uint16_t)yb; d[3] = (uint16_t)(yb >> 16);
-	d[4] = (uint16_t)(color[0] | (color[1] << 8));
-	d[5] = (uint16_t)(color[2] | ((center & 0xFF) << 8));
-	d[6] = (uint16_t)(((center >> 8) & 0xFF) | (((center >> 16) & 0xFF) << 8));
-	d[7] = (uint16_t)cb; d[8] = (uint16_t)(cb >> 16);
-	d[9] = (uint16_t)sb; d[10] = (uint16_t)(sb >> 16);
+	st_wt16(d + 0, xb); st_wt16(d + 1, xb >> 16);
+	st_wt16(d + 2, yb); st_wt16(d + 3, yb >> 16);
+	st_wt16(d + 4, color[0] | (color[1] << 8));
+	st_wt16(d + 5, color[2] | ((center & 0xFF) << 8));
+	st_wt16(d + 6, ((center >> 8) & 0xFF) | (((center >> 16) & 0xFF) << 8));
+	st_wt16(d + 7, cb); st_wt16(d + 8, cb >> 16);
+	st_wt16(d + 9, sb); st_wt16(d + 10, sb >> 16);
 }
 
 // disc statistics of blobList.cl:57-78 by one wavefront; all lanes return the same values
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 					const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
 					const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
 					store_match(rec_work + ((size_t)z * max_matches + i) * 22, mx, my, color, f[pix], v, score);
-					idx_work[(size_t)z * max_matches + i] = pix;
+					__hip_atomic_store((gu32_t*)(idx_work + (size_t)z * max_matches + i), pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 			}
 		}
@@ -247,16 +257,17 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 		}
 	}
 
-	// ---- arrival: every record store of this workgroup is visible device-wide before its arrival is counted ------------------
-	__threadfence();
+	// ---- arrival (Guideline 16, R1): the records were stored write-through; every storing wave drains its stores, the workgroup meets
+	// at a barrier, then ONE lane counts the arrival with an agent-scope atomic.  The workgroup whose add came last (told by the value the
+	// add returned) takes ONE agent-scope acquire and then reads what the others wrote.
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	if(threadIdx.x == 0) {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		s_last = atomicAdd(&done[z], 1) == (int)gridDim.x - 1;
-	}
+	if(threadIdx.x == 0) s_last = atomicAdd(&done[z], 1) == (int)gridDim.x - 1;
 	__syncthreads();
 	if(!s_last) return;
-	__threadfence(); // acquire: the other workgroups' records and counters
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
 	if(threadIdx.x == 0) { // self-cleaning: every workgroup of this frame has read cand_count and arrived
 		cand_count[z] = 0;
 		done[z] = 0;
@@ -267,11 +278,11 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 	const uint32_t* id = idx_work + (size_t)z * max_matches;
 	for(int t0 = 0; t0 < nrec; t0 += 256) {
 		const int t = t0 + (int)threadIdx.x;
-		const uint32_t mine = t < nrec ? id[t] : 0;
+		const uint32_t mine = t < nrec ? ld_wt32(id + t) : 0;
 		int rank = 0;
 		for(int j0 = 0; j0 < nrec; j0 += 256) {
 			const int j = j0 + (int)threadIdx.x;
-			tile[threadIdx.x] = j < nrec ? id[j] : 0xFFFFFFFFu;
+			tile[threadIdx.x] = j < nrec ? ld_wt32(id + j) : 0xFFFFFFFFu;
 			__syncthreads();
 			const int m = min(256, nrec - j0);
 			for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + ((size_t)z * max_matches + t) * 22);
 			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + ((size_t)z * max_matches + rank) * 22);
 #pragma unroll
-			for(int k = 0; k < 11; k++) dp[k] = sp[k];
+			for(int k = 0; k < 11; k++) dp[k] = ld_wt16(sp + k);
 			if(idx_sorted) idx_sorted[(size_t)z * max_matches + rank] = mine;
 		}
 	}
@@ -300,34 +311,37 @@ __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ a, int na) {
 //   pp(x, y) = Bx(x+1, y+1),  nn = Bx(x-r, y-r),  pn = -Bx(x+1, y-r),  np = -Bx(x-r, y+1)
 // and Bx separates into row differences: with  D1(row) = S(x+r, row) - S(x+1, row)  and  D2(row) = S(x-1, row) - S(x-r, row)
 //   pp = D1(y+r) - D1(y+1),   -Bx(x+1, y-r) = D1(y-r) - D1(y-1),   -Bx(x-r, y+1) = D2(y+1) - D2(y+r),   nn = D2(y-1) - D2(y-r).
-// So a lane that owns image column x and WALKS DOWN the rows needs four SAT values per row (columns x+r, x+1, x-1, x-r of row
-// y+r: coalesced dword loads with a scalar row offset, clamp-to-edge folded into the per-lane column offsets and the scalar row
-// index) and keeps the last 2r+1 values of D1 and D2 in registers: 4 loads + ~20 VALU instructions per pixel, no LDS, no barrier,
-// no index arithmetic in the loop.  Wrapping int32 differences are exact; min(min(pp,nn),min(pn,np)) is taken on the
-// integers and converted once (int -> float is monotonic, so the converted minimum is the minimum of the converted values).
+// So a lane that owns image column x and WALKS DOWN the rows needs four SAT values of row y+r -- columns x+r, x+1, x-1, x-r -- and
+// keeps the last 2r+1 values of D1 and D2 in registers: ~25 VALU instructions per pixel, no LDS memory, no barrier, no index
+// arithmetic in the loop.  The four values are ONE coalesced dword load per lane (its own column, clamp-to-edge folded into the
+// per-lane column offset and the scalar row index) shifted across the wavefront: +-1 by DPP wave shifts, +-r by ds_bpermute (the LDS
+// crossbar, no LDS memory).  [Four loads per lane and row kept the texture addresser busy 84 % of the kernel; one load does not.]
+// Wrapping int32 differences are exact; min(min(pp,nn),min(pn,np)) is taken on the integers and converted once
+// (int -> float is monotonic, so the converted minimum is the minimum of the converted values).
 // The peak test needs blobCenter of the four neighbours: up / down are the lane's own previous / next row, left / right come from
-// the neighbouring lanes by DPP wave shifts.  A wavefront therefore covers 62 image columns (lanes 1..62) plus one column of
-// each neighbour strip (lanes 0, 63), and `seg_h` rows plus the 2r+2 rows it needs to get going.  Neighbours outside the image
-// take the pixel's own value: that is what the reference's clamped reads return, and `own > own` is false.
-constexpr int WK_COLS = 62;
+// the neighbouring lanes by DPP wave shifts again.  A wavefront therefore yields 62 - 2r image columns (lanes r+1 .. 62-r; the
+// lanes around them only carry the neighbours' columns) and `seg_h` rows plus the 2r+2 rows it needs to get going.  Neighbours
+// outside the image take the pixel's own value: that is what the reference's clamped reads return, and `own > own` is false.
 
 template<int RT, bool BCOUT>
 __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
 		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int seg_h, int strips_x, int segs_y, unsigned n_items, int cap, float thr) {
-	constexpr int R = RT, PF = 4, WL = ((2 * R + 1 + PF - 1) / PF) * PF;
+	constexpr int R = RT, PF = 4, WL = ((2 * R + 1 + PF - 1) / PF) * PF, USE = 62 - 2 * R; // USE: image columns a wavefront yields
 	const int lane = threadIdx.x & 63;
-	// XCD-aware: each XCD walks a contiguous run of work items (strips of one segment row are neighbours), so the 2r+2 columns
-	// adjacent strips share are L2 hits.  Speed only.
+	// XCD-aware: each XCD walks a contiguous run of work items (strips of one segment row are neighbours), so the columns adjacent
+	// strips share are L2 hits.  Speed only.
 	const unsigned item = __builtin_amdgcn_readfirstlane(vp_xcd_remap(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6));
 	if(item >= n_items) return; // the whole wavefront
 	const int strip = (int)(item % (unsigned)strips_x), t1 = (int)(item / (unsigned)strips_x), seg = t1 % segs_y, z = t1 / segs_y;
 	const int ya = seg * seg_h, yb = min(h, ya + seg_h);
-	const int x = strip * WK_COLS - 1 + lane, xc = vp_clampi(x, 0, w - 1);
-	const uint32_t oa = 4u * (uint32_t)min(xc + R, w - 1), ob = 4u * (uint32_t)min(xc + 1, w - 1), oc = 4u * (uint32_t)max(xc - 1, 0), od = 4u * (uint32_t)max(xc - R, 0);
+	const int x = strip * USE - (R + 1) + lane;
+	const uint32_t oe = 4u * (uint32_t)vp_clampi(x, 0, w - 1);
+	int perm_hi = 4 * ((lane + R) & 63), perm_lo = 4 * ((lane - R) & 63); // ds_bpermute byte addresses: lane l reads lane l + r / l - r (mod 64)
+	asm volatile("" : "+v"(perm_hi), "+v"(perm_lo)); // opaque: keeps the compiler from splitting them into base + the instruction's offset field
 	const size_t n = (size_t)w * h;
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sat_all + z * n), 0, (int)(n * 4), 0x00020000); // host: n * 4 < 2^31
 	const uint32_t row_bytes = (uint32_t)w * 4u;
-	const bool col_ok = lane >= 1 && lane <= WK_COLS && x < w;
+	const bool col_ok = lane >= R + 1 && lane <= 62 - R && x < w; // (x >= 0 for these lanes)
 	const bool x_first = x == 0, x_last = x == w - 1;
 	const float div = (float)(R * R), rcp = 1.0f / div;
 	auto quot = [&](float m) {
@@ -339,10 +353,10 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 		}
 		return m / div;
 	};
-	// Windows of the last WL >= 2r+1 rows of D1 / D2, and the raw SAT values of the next PF rows in flight: a row's four loads are
-	// issued PF steps before they are used (a walk is one dependent chain per lane; without the run-ahead every step would wait a full
+	// Windows of the last WL >= 2r+1 rows of -D1 / D2, and the raw SAT values of the next PF rows in flight: a row's load is
+	// issued PF steps before it is used (a walk is one dependent chain per lane; without the run-ahead every step would wait a full
 	// memory round trip).  WL is a multiple of PF and the loop is unrolled WL-fold, so every array index below is a constant.
-	int D1[WL], D2[WL], Pa[PF], Pb[PF], Pc[PF], Pd[PF];
+	int D1[WL], D2[WL], Pe[PF];
 #pragma unroll
 	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
 	float up = 0.f, mid = 0.f; // blobCenter of rows t-2, t-1 while row t is being formed
@@ -353,10 +367,7 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 #define VP_WK_ISSUE(SLOT, K)                                                                                                           \
 	do {                                                                                                                               \
 		const uint32_t soff_ = (uint32_t)vp_clampi(s0 + (K) + R, 0, h - 1) * row_bytes; /* SAT row t + r, clamp-to-edge (satBlobCenter.cl:20) */ \
-		Pa[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oa, soff_, 0);                                                             \
-		Pb[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, ob, soff_, 0);                                                             \
-		Pc[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oc, soff_, 0);                                                             \
-		Pd[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, od, soff_, 0);                                                             \
+		Pe[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oe, soff_, 0);                                                             \
 	} while(0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_WK_ISSUE(p, p);
@@ -364,11 +375,20 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 #pragma unroll
 		for(int j = 0; j < WL; j++) {
 			const int k = kb + j;
-			D1[j] = (int)((uint32_t)Pa[j % PF] - (uint32_t)Pb[j % PF]);
-			D2[j] = (int)((uint32_t)Pc[j % PF] - (uint32_t)Pd[j % PF]);
+			{
+				const int e = Pe[j % PF]; // S(clamp(x), row); the taps at clamp(x +- 1), clamp(x +- r) sit in the neighbouring lanes
+				const int sa = __builtin_amdgcn_ds_bpermute(perm_hi, e), sd = __builtin_amdgcn_ds_bpermute(perm_lo, e);
+				const int sb = __builtin_amdgcn_update_dpp(0, e, 0x130, 0xf, 0xf, false), sc = __builtin_amdgcn_update_dpp(0, e, 0x138, 0xf, 0xf, false); // lane + 1, lane - 1
+				// NOTE the operand order: a DPP-shifted value is only ever the MINUEND.  hipcc folds the shift into the subtraction, and for a
+				// shifted SUBTRAHEND it emits v_subrev_u32_dpp, which on gfx950 (ROCm 7.2) shifts the OTHER operand: a - shl(e) comes out as
+				// shl(a) - e (tools/dbg/dpp_test.hip shows it in isolation; tests/test_capi_symbols.py checks that no such instruction is
+				// in the library).  So the first window holds N1 = -D1 = S(x+1) - S(x+r).
+				D1[j] = (int)((uint32_t)sb - (uint32_t)sa);
+				D2[j] = (int)((uint32_t)sc - (uint32_t)sd);
+			}
 			VP_WK_ISSUE(j % PF, k + PF);
 			const int jp1 = (j - R + 1 + 2 * WL) % WL, jm1 = (j - R - 1 + 2 * WL) % WL, jmr = (j - 2 * R + 2 * WL) % WL; // rows t+1, t-1, t-r (row t+r is j)
-			const int pp = (int)((uint32_t)D1[j] - (uint32_t)D1[jp1]), pn = (int)((uint32_t)D1[jmr] - (uint32_t)D1[jm1]);
+			const int pp = (int)((uint32_t)D1[jp1] - (uint32_t)D1[j]), pn = (int)((uint32_t)D1[jm1] - (uint32_t)D1[jmr]); // D1[] holds -D1 (see above)
 			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
 			const float dn = quot((float)min(min(pp, nn), min(pn, np))); // blobCenter(x, t), t = s0 + k
 			const int t = s0 + k;
@@ -478,7 +498,7 @@ int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, con
 		return vp_launch_ok("blobList emit");
 	}
 	if(circle_radius >= 2 && circle_radius <= 12 && (size_t)w * h * 4 < 0x7fffffffu) {
-		const int strips_x = (int)vp_div_up(w, WK_COLS);
+		const int strips_x = (int)vp_div_up(w, 62 - 2 * circle_radius);
 		// rows per wavefront: long walks amortise the 2r+2 start-up rows, short ones give a small launch enough wavefronts
 		int seg_h = ctx->tune.tail_segment_rows;
 		if(seg_h <= 0) {
