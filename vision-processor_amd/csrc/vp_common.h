@@ -55,7 +55,8 @@ struct VpContext {
 	int n_streams = 0;
 	bool own_streams = true;
 	hipStream_t streams[VP_MAX_STREAMS] = {};
-	VpWorkspace ws[4][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, sort temp); slot 1: persistent SAT tile carries; slot 2: coordinate map; slot 3: halo strips
+	VpWorkspace ws[5][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, append-order records); slot 1: persistent SAT tile carries; slot 2: coordinate map; slot 3: halo strips;
+	                                     // slot 4: self-cleaning counters of the blob list (zero between launches: nothing else may ever be placed there)
 	unsigned char map_key[VP_MAX_STREAMS][96] = {}; // geometry the cached coordinate map of each stream was built for
 	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // generation tag of the single-pass SAT carry granules
 	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tickets handed out per frame queue by all earlier launches on this stream (mod 2^32)

@@ -51,12 +51,12 @@ extern "C" int vp_blobcenter(VpContext* ctx, int stream, const int32_t* sat, int
 }
 
 // ---------------------------------------------------------------- blobList -----------------------------------------
-// Workspace of one list call (slot 0 of the stream).  The two counter arrays sit at the START of the workspace and are
-// SELF-CLEANING: the emit kernel's last workgroup of a frame puts cand_count / done back to zero, so no launch has to clear
-// them (the workspace is zero-filled when it is allocated; every layout keeps them at offset 0).
+// Workspace of one list call.  The two counter arrays live in a workspace slot of their own (slot 4) and are SELF-CLEANING: the
+// last workgroup of a frame puts cand_count / done back to zero, so no launch has to clear them (a workspace is zero-filled when
+// it is allocated or grows, and nothing else is ever placed in that slot).  The lists are per-call scratch (slot 0).
 struct ListScratch {
 	int32_t* cand_count;  // batch   candidates found by the detect pass (may exceed cap: the emit pass then rescans the frame)
-	int32_t* done;        // batch   emit workgroups finished (last-workgroup-done pattern)
+	int32_t* done;        // batch x ARRIVE_WORDS   arrival counters of the last-workgroup-done pattern (frame_arrive_and_sort)
 	uint32_t* cand;       // batch x cap   candidate pixel indices
 	uint32_t* idx;        // batch x max  (append-order idx: RASTER order, or when the caller passes none)
 	uint8_t* rec_tmp;     // batch x max x 22   append-order records (RASTER order only)
@@ -65,19 +65,25 @@ struct ListScratch {
 
 static size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
+// Arrival counters of one frame: up to ARRIVE_SHARDS shard counters + one top counter, each on a 64-byte line of its own.  A single
+// counter per frame serialises the arrivals (one returning atomic per workgroup on ONE address: ~88 per microsecond, measured as
+// +11 us on a single frame with 960 workgroups); with shards a workgroup adds to its shard, and only the last arriver of a shard
+// adds to the top counter.
+constexpr int ARRIVE_SHARDS = 64, ARRIVE_LINE = 16, ARRIVE_WORDS = (ARRIVE_SHARDS + 1) * ARRIVE_LINE;
+
 // The candidate list is bounded: cap = max(4 * max_matches, 4096) entries per frame (vp_ctx_tune "candidate_capacity" overrides).
 // A frame with more thresholded local maxima than that is still processed exactly: the emit pass sees cand_count > cap and
 // rescans the frame itself instead of reading the list (slow, pathological inputs only).
 static int list_scratch(VpContext* ctx, int stream, int batch, int max_matches, ListScratch* s) {
 	const int cap = ctx->tune.candidate_capacity > 0 ? ctx->tune.candidate_capacity : (max_matches > 1024 ? 4 * max_matches : 4096);
-	const size_t b_cnt = align256(sizeof(int32_t) * 2 * batch), b_cand = align256(sizeof(uint32_t) * (size_t)cap * batch);
+	const size_t b_cnt = align256(sizeof(int32_t) * (1 + ARRIVE_WORDS) * (size_t)batch), b_cand = align256(sizeof(uint32_t) * (size_t)cap * batch);
 	const size_t b_idx = align256(sizeof(uint32_t) * (size_t)max_matches * batch), b_rec = align256((size_t)22 * max_matches * batch);
-	void* base = nullptr;
-	VP_TRY(vp_workspace(ctx, stream, 0, b_cnt + b_cand + b_idx + b_rec, &base));
+	void *base = nullptr, *cnt = nullptr;
+	VP_TRY(vp_workspace(ctx, stream, 4, b_cnt, &cnt));
+	VP_TRY(vp_workspace(ctx, stream, 0, b_cand + b_idx + b_rec, &base));
+	s->done = static_cast<int32_t*>(cnt); // [batch][ARRIVE_WORDS], then cand_count[batch]: the offset of a frame's words does not depend on the batch
+	s->cand_count = s->done + (size_t)ARRIVE_WORDS * batch;
 	uint8_t* p = static_cast<uint8_t*>(base);
-	s->cand_count = reinterpret_cast<int32_t*>(p);
-	s->done = s->cand_count + batch;
-	p += b_cnt;
 	s->cand = reinterpret_cast<uint32_t*>(p); p += b_cand;
 	s->idx = reinterpret_cast<uint32_t*>(p); p += b_idx;
 	s->rec_tmp = p;
@@ -177,10 +183,85 @@ __device__ __forceinline__ float disc_score_wave(const uint32_t* __restrict__ f,
 	return circ / (sd[0] + sd[1] + sd[2]);       // :78
 }
 
+// Last-workgroup-done (cdna_hip_programming.md Guideline 16, R1): the records of a frame were stored write-through by whichever
+// workgroups found them; every storing wave drains its stores, the workgroup meets at a barrier, then ONE lane counts the arrival
+// with an agent-scope atomic.  The workgroup whose add came last (told by the value the add returned) takes ONE agent-scope acquire,
+// reads the records with sc1 loads, sorts them by pixel index into the caller's arrays when the order is RASTER, and puts the
+// self-cleaning counters back to zero: no separate sort launch, no clearing launch.  Called by all 256 threads of a workgroup.
+__device__ __forceinline__ void frame_arrive_and_sort(int32_t* done /* this frame's ARRIVE_WORDS */, int wg /* this workgroup's number within the frame */, int n_workgroups,
+		int32_t* cand_count, int32_t* counter, const uint8_t* rec_work, const uint32_t* idx_work,
+		int max_matches, int order, uint8_t* rec_sorted, uint32_t* idx_sorted, uint32_t* tile /* LDS [256] */, int* s_last /* LDS */) {
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if(threadIdx.x == 0) {
+		const int per = (n_workgroups + ARRIVE_SHARDS - 1) / ARRIVE_SHARDS, shard = wg / per, n_shards = (n_workgroups + per - 1) / per;
+		const int in_shard = min(per, n_workgroups - shard * per);
+		int last = 0;
+		if(atomicAdd(done + shard * ARRIVE_LINE, 1) == in_shard - 1) {
+			__hip_atomic_store(done + shard * ARRIVE_LINE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // self-cleaning
+			last = atomicAdd(done + ARRIVE_SHARDS * ARRIVE_LINE, 1) == n_shards - 1;
+		}
+		*s_last = last;
+	}
+	__syncthreads();
+	if(!*s_last) return;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if(threadIdx.x == 0) { // self-cleaning: every workgroup of this frame has arrived
+		if(cand_count) *cand_count = 0;
+		done[ARRIVE_SHARDS * ARRIVE_LINE] = 0;
+	}
+	if(order != VP_ORDER_RASTER) return;
+	// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique)
+	const int nrec = min(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), max_matches);
+	for(int t0 = 0; t0 < nrec; t0 += 256) {
+		const int t = t0 + (int)threadIdx.x;
+		const uint32_t mine = t < nrec ? ld_wt32(idx_work + t) : 0;
+		int rank = 0;
+		for(int j0 = 0; j0 < nrec; j0 += 256) {
+			const int j = j0 + (int)threadIdx.x;
+			tile[threadIdx.x] = j < nrec ? ld_wt32(idx_work + j) : 0xFFFFFFFFu;
+			__syncthreads();
+			const int m = min(256, nrec - j0);
+			for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
+			__syncthreads();
+		}
+		if(t < nrec) {
+			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + (size_t)t * 22);
+			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + (size_t)rank * 22);
+#pragma unroll
+			for(int k = 0; k < 11; k++) dp[k] = ld_wt16(sp + k);
+			if(idx_sorted) idx_sorted[rank] = mine;
+		}
+	}
+}
+
+// One surviving candidate -> one record (blobList.cl:57-102), by a whole wavefront: disc statistics, score, the atomic append.
+// v = blobCenter at the peak, nx / qx / ny / qy its left / right / upper / lower neighbours (clamp-to-edge values).
+__device__ __forceinline__ void emit_record(const uint32_t* __restrict__ f, int w, int h, int px, int py, float v, float nx, float qx, float ny, float qy,
+		float min_score, int radius, int max_matches, int32_t* counter /* frame's [3] */, uint8_t* rec_work, uint32_t* idx_work, int lane) {
+	uint32_t color[3];
+	const float score = disc_score_wave(f, w, h, px, py, radius, v, color);
+	if(lane == 0) {
+		if(score < min_score) { // :79-82 (NaN is kept)
+			atomicAdd(&counter[1], 1);
+		} else {
+			const int i = atomicAdd(&counter[0], 1); // :87
+			if(i < max_matches) {                   // :88-89
+				const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
+				const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
+				const uint32_t pix = (uint32_t)(py * w + px);
+				store_match(rec_work + (size_t)i * 22, mx, my, color, f[pix], v, score);
+				__hip_atomic_store((gu32_t*)(idx_work + i), pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+}
+
 // blobList.cl:57-102, one wavefront per candidate.  FROM_SAT: blobCenter was never materialised; the five values the record
 // needs (centre + 4 neighbours, clamp-to-edge) are recomputed from the SAT by lanes 0-4.
-// The LAST workgroup of a frame to finish (arrival counter `done`) sorts the frame's records by pixel index into the caller's
-// arrays when the order is RASTER, and puts the self-cleaning counters back to zero: no separate sort launch, no clearing launch.
+// The LAST workgroup of a frame to finish sorts the frame's records (frame_arrive_and_sort).
 template<bool FROM_SAT>
 __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat, const void* __restrict__ src, const uint32_t* __restrict__ cand,
 		int32_t* __restrict__ cand_count, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work, uint32_t* __restrict__ idx_work,
@@ -210,21 +291,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 			nx = bc_tap(c, w, h, px - 1, py); qx = bc_tap(c, w, h, px + 1, py);
 			ny = bc_tap(c, w, h, px, py - 1); qy = bc_tap(c, w, h, px, py + 1);
 		}
-		uint32_t color[3];
-		const float score = disc_score_wave(f, w, h, px, py, radius, v, color);
-		if(lane == 0) {
-			if(score < min_score) { // :79-82 (NaN is kept)
-				atomicAdd(&counter[3 * z + 1], 1);
-			} else {
-				const int i = atomicAdd(&counter[3 * z], 1); // :87
-				if(i < max_matches) {                        // :88-89
-					const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
-					const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
-					store_match(rec_work + ((size_t)z * max_matches + i) * 22, mx, my, color, f[pix], v, score);
-					__hip_atomic_store((gu32_t*)(idx_work + (size_t)z * max_matches + i), pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-			}
-		}
+		emit_record(f, w, h, px, py, v, nx, qx, ny, qy, min_score, radius, max_matches, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, lane);
 	};
 
 	if(total <= cap) {
@@ -257,45 +324,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint32_t* __restrict__ flat,
 		}
 	}
 
-	// ---- arrival (Guideline 16, R1): the records were stored write-through; every storing wave drains its stores, the workgroup meets
-	// at a barrier, then ONE lane counts the arrival with an agent-scope atomic.  The workgroup whose add came last (told by the value the
-	// add returned) takes ONE agent-scope acquire and then reads what the others wrote.
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	if(threadIdx.x == 0) s_last = atomicAdd(&done[z], 1) == (int)gridDim.x - 1;
-	__syncthreads();
-	if(!s_last) return;
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	if(threadIdx.x == 0) { // self-cleaning: every workgroup of this frame has read cand_count and arrived
-		cand_count[z] = 0;
-		done[z] = 0;
-	}
-	if(order != VP_ORDER_RASTER) return;
-	// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique)
-	const int nrec = min(__hip_atomic_load(&counter[3 * z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), max_matches);
-	const uint32_t* id = idx_work + (size_t)z * max_matches;
-	for(int t0 = 0; t0 < nrec; t0 += 256) {
-		const int t = t0 + (int)threadIdx.x;
-		const uint32_t mine = t < nrec ? ld_wt32(id + t) : 0;
-		int rank = 0;
-		for(int j0 = 0; j0 < nrec; j0 += 256) {
-			const int j = j0 + (int)threadIdx.x;
-			tile[threadIdx.x] = j < nrec ? ld_wt32(id + j) : 0xFFFFFFFFu;
-			__syncthreads();
-			const int m = min(256, nrec - j0);
-			for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
-			__syncthreads();
-		}
-		if(t < nrec) {
-			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + ((size_t)z * max_matches + t) * 22);
-			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + ((size_t)z * max_matches + rank) * 22);
-#pragma unroll
-			for(int k = 0; k < 11; k++) dp[k] = ld_wt16(sp + k);
-			if(idx_sorted) idx_sorted[(size_t)z * max_matches + rank] = mine;
-		}
-	}
+	frame_arrive_and_sort(done + (size_t)z * ARRIVE_WORDS, (int)blockIdx.x, (int)gridDim.x, cand_count + z, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, max_matches, order,
+			rec_sorted + (size_t)z * max_matches * 22, idx_sorted ? idx_sorted + (size_t)z * max_matches : nullptr, tile, &s_last);
 }
 
 __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ a, int na) {
@@ -324,21 +354,27 @@ __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ a, int na) {
 // outside the image take the pixel's own value: that is what the reference's clamped reads return, and `own > own` is false.
 
 template<int RT, bool BCOUT>
-__global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, uint32_t* __restrict__ cand,
-		int32_t* __restrict__ cand_count, int32_t* __restrict__ counter, int w, int h, int seg_h, int strips_x, int segs_y, unsigned n_items, int cap, float thr) {
+__global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, const uint32_t* __restrict__ flat, int32_t* __restrict__ done,
+		int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work, uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame,
+		float thr, float min_score, int list_radius, int max_matches, int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+	__shared__ uint32_t tile[256];
+	__shared__ int s_last;
 	constexpr int R = RT, PF = 4, WL = ((2 * R + 1 + PF - 1) / PF) * PF, USE = 62 - 2 * R; // USE: image columns a wavefront yields
 	const int lane = threadIdx.x & 63;
-	// XCD-aware: each XCD walks a contiguous run of work items (strips of one segment row are neighbours), so the columns adjacent
-	// strips share are L2 hits.  Speed only.
-	const unsigned item = __builtin_amdgcn_readfirstlane(vp_xcd_remap(blockIdx.x, gridDim.x) * 4u + (threadIdx.x >> 6));
-	if(item >= n_items) return; // the whole wavefront
-	const int strip = (int)(item % (unsigned)strips_x), t1 = (int)(item / (unsigned)strips_x), seg = t1 % segs_y, z = t1 / segs_y;
+	// A workgroup = 4 independent wavefronts of ONE frame (the frame's work items are padded to a multiple of 4, so that the workgroup can
+	// take part in that frame's arrival count).  XCD-aware: each XCD walks a contiguous run of workgroups (strips of one segment row are
+	// neighbours), so the columns adjacent strips share are L2 hits.  Speed only.
+	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
+	const int z = (int)(lb / (unsigned)wgs_per_frame);
+	const int item = __builtin_amdgcn_readfirstlane((int)(lb - (unsigned)z * (unsigned)wgs_per_frame) * 4 + (int)(threadIdx.x >> 6));
+	const size_t n = (size_t)w * h;
+	if(item < items_per_frame) { // wave-uniform: the padding wavefronts only take part in the arrival below
+	const int strip = item % strips_x, seg = item / strips_x;
 	const int ya = seg * seg_h, yb = min(h, ya + seg_h);
 	const int x = strip * USE - (R + 1) + lane;
 	const uint32_t oe = 4u * (uint32_t)vp_clampi(x, 0, w - 1);
 	int perm_hi = 4 * ((lane + R) & 63), perm_lo = 4 * ((lane - R) & 63); // ds_bpermute byte addresses: lane l reads lane l + r / l - r (mod 64)
 	asm volatile("" : "+v"(perm_hi), "+v"(perm_lo)); // opaque: keeps the compiler from splitting them into base + the instruction's offset field
-	const size_t n = (size_t)w * h;
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sat_all + z * n), 0, (int)(n * 4), 0x00020000); // host: n * 4 < 2^31
 	const uint32_t row_bytes = (uint32_t)w * 4u;
 	const bool col_ok = lane >= R + 1 && lane <= 62 - R && x < w; // (x >= 0 for these lanes)
@@ -361,7 +397,7 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
 	float up = 0.f, mid = 0.f; // blobCenter of rows t-2, t-1 while row t is being formed
 	int rej = 0;
-	uint32_t* cand_frame = cand + (size_t)z * cap;
+	const uint32_t* fz = flat + z * n;
 	const int s0 = ya - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ya - 1 at k = 2r, when the windows are full
 	const int nsteps = 2 * R + (yb - ya) + 2;
 #define VP_WK_ISSUE(SLOT, K)                                                                                                           \
@@ -404,7 +440,18 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 				const bool above = col_ok && !(v < thr);                                   // blobList.cl:39
 				const bool peak = !(lf > v || rt > v || uv > v || dv > v);                 // :47-52, strict '>'
 				rej += __popcll(__ballot(above && !peak));                                 // :53 counter[2]++
-				wave_append(above && peak, (uint32_t)(y * w + x), cand_frame, cand_count + z, cap, lane);
+				// survivors (rare: ~130 per frame) are turned into records right here, one at a time by the whole wavefront -- the peak's
+				// value and its four neighbours are at hand, so nothing is recomputed and no candidate list exists (blobList.cl:57-102)
+				unsigned long long cm = __ballot(above && peak);
+				while(cm != 0) { // wave-uniform
+					const int b = __ffsll((long long)cm) - 1;
+					cm &= cm - 1;
+					const int px = __builtin_amdgcn_readlane(x, b);
+					const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
+					const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), b)), cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rt), b));
+					const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uv), b)), cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), b));
+					emit_record(fz, w, h, px, y, cv, cl, cr, cu, cd, min_score, list_radius, max_matches, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, lane);
+				}
 			}
 			up = mid;
 			mid = dn;
@@ -412,7 +459,11 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	}
 #undef VP_WK_ISSUE
 	if(rej != 0 && lane == 0) atomicAdd(&counter[3 * z + 2], rej);
+	} // item < items_per_frame
+	frame_arrive_and_sort(done + (size_t)z * ARRIVE_WORDS, (int)(lb - (unsigned)z * (unsigned)wgs_per_frame), wgs_per_frame, nullptr, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, max_matches, order,
+			rec_sorted + (size_t)z * max_matches * 22, idx_sorted ? idx_sorted + (size_t)z * max_matches : nullptr, tile, &s_last);
 }
+
 
 // Run-time radius fallback (radii outside the specialised range): the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge
 // addressing (satBlobCenter.cl:20, H7), the box-sum image Bx and then blobCenter for the 64x64 tile plus a 1-pixel ring are built in
@@ -474,8 +525,9 @@ __global__ __launch_bounds__(FT_NT) void k_circle_detect(const int32_t* __restri
 	if(rej != 0 && (tid & 63) == 0) atomicAdd(&counter[3 * z + 2], rej);
 }
 
-// blobcenter != nullptr: list from a materialised blobCenter image (vp_bloblist).  Otherwise fused from the SAT
-// (vp_blobcenter_list): blobCenter stays in registers, `bc_out` (optional) receives the debug view.
+// blobcenter != nullptr: list from a materialised blobCenter image (vp_bloblist: detect -> candidate list -> emit).  Otherwise fused
+// from the SAT (vp_blobcenter_list): one launch of the register walker for radii 2..12 (blobCenter stays in registers, `bc_out`
+// (optional) receives the debug view); other radii take the LDS fallback + the emit kernel.
 // counters_zeroed: the caller's counter[3 x batch] was already cleared on this stream (vp_frame lets the SAT kernel do it).
 int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
 		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed) {
@@ -498,6 +550,7 @@ int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, con
 		return vp_launch_ok("blobList emit");
 	}
 	if(circle_radius >= 2 && circle_radius <= 12 && (size_t)w * h * 4 < 0x7fffffffu) {
+		// the register walker: circle + detect + record emission + sort in ONE launch, no candidate list
 		const int strips_x = (int)vp_div_up(w, 62 - 2 * circle_radius);
 		// rows per wavefront: long walks amortise the 2r+2 start-up rows, short ones give a small launch enough wavefronts
 		int seg_h = ctx->tune.tail_segment_rows;
@@ -510,18 +563,21 @@ int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, con
 				}
 		}
 		const int segs_y = (int)vp_div_up(h, seg_h);
-		const long long items = (long long)strips_x * segs_y * batch;
-		VP_REQUIRE(items < (1ll << 31), "vp_blobcenter_list: too many work items");
-		const unsigned grid = (unsigned)((items + 3) / 4);
+		const long long ipf = (long long)strips_x * segs_y, wpf = (ipf + 3) / 4; // work items and workgroups per frame
+		VP_REQUIRE(wpf * batch < (1ll << 31) && ipf < (1ll << 30), "vp_blobcenter_list: too many work items");
+		const unsigned grid = (unsigned)(wpf * batch);
+		const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flat);
+		uint8_t* msorted = reinterpret_cast<uint8_t*>(matches);
 #define VP_WK(R) \
 		case R: \
-			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, seg_h, strips_x, segs_y, (unsigned)items, ws.cap, thr); \
-			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, ws.cand, ws.cand_count, counter, w, h, seg_h, strips_x, segs_y, (unsigned)items, ws.cap, thr); \
+			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, min_score, radius, max_matches, order, msorted, idx); \
+			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, min_score, radius, max_matches, order, msorted, idx); \
 			break
 		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale))
 			VP_WK(2); VP_WK(3); VP_WK(4); VP_WK(5); VP_WK(6); VP_WK(7); VP_WK(8); VP_WK(9); VP_WK(10); VP_WK(11); VP_WK(12);
 		}
 #undef VP_WK
+		return vp_launch_ok("circle+blobList");
 	} else {
 		const int halo = circle_radius + 1;
 		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
