@@ -149,6 +149,81 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
+def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, counter, idx, B):
+    """Measurements beside the headline (BASELINE.json configs[2] and the figures DESIGN.md quotes), taken AFTER the timed region on the same
+    resident frames; none of them is `value`.  Returns a dict for the `extras` key."""
+    out = {}
+    mm = cfg.max_matches
+    ctx = capi.Context(0, n_streams=8)  # library-owned streams: frames of different cameras in flight
+    try:
+        def rate(fn, n, frames_per_call):
+            for _ in range(3):
+                fn()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            ctx.sync()
+            return frames_per_call * n / (time.perf_counter() - t0)
+
+        # frames per launch group (one stream): throughput against batching
+        sweep = {}
+        for b in (1, 8, 32, B):
+            if b > B:
+                continue
+            sweep[str(b)] = round(rate(lambda: ctx.frame(params, d_raw, b, flat, sat, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
+        out["frames_per_s_by_frames_per_launch"] = sweep
+        # one frame, host-synchronised after every frame: latency of the whole hot path
+        n = 200
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.frame(params, d_raw, 1, flat, sat, matches, counter, idx=idx, stream=0)
+            ctx.sync(0)
+        out["single_frame_latency_us"] = round(1e6 * (time.perf_counter() - t0) / n, 1)
+        # BASELINE configs[2]: s streams in flight, b frames per launch on each (own buffers per stream)
+        per = 8
+        bufs = [dict(flat=torch.empty((per, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.empty((per, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+                     m=torch.zeros((per, 22 * mm), dtype=torch.uint8, device="cuda"), i=torch.zeros((per, mm), dtype=torch.int32, device="cuda"),
+                     c=torch.zeros((per, 3), dtype=torch.int32, device="cuda")) for _ in range(8)]
+        torch.cuda.synchronize()
+        streams = {}
+        for ns, b in ((1, 1), (2, 1), (4, 1), (8, 1), (2, 8), (4, 8), (8, 8)):
+            def go():
+                for st in range(ns):
+                    u = bufs[st]
+                    ctx.frame(params, d_raw[st * b:], b, u["flat"], u["sat"], u["m"], u["c"], idx=u["i"], stream=st)
+            streams[f"{ns}x{b}"] = round(rate(go, 100 if b == 1 else 30, ns * b), 1)
+        out["frames_per_s_streams_x_frames_per_launch"] = streams
+        # PCIe-inclusive: pinned host frames -> H2D -> vp_frame -> D2H of counters + records, 8 frames per copy and launch group, two streams
+        g = min(per, B)
+        h_raw = torch.from_numpy(np.ascontiguousarray(d_raw[:g].cpu().numpy())).pin_memory()
+        h_m = [torch.zeros((g, 22 * mm), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        h_c = [torch.zeros((g, 3), dtype=torch.int32).pin_memory() for _ in range(2)]
+        d_in = [torch.empty_like(d_raw[:g]) for _ in range(2)]
+        torch.cuda.synchronize()
+        lib = capi.lib()
+        import ctypes as C
+
+        def pcie(k):
+            st = k & 1
+            u = bufs[st]
+            lib.vp_copy_h2d(ctx.h, st, C.c_void_p(d_in[st].data_ptr()), C.c_void_p(h_raw.data_ptr()), C.c_size_t(h_raw.numel()))
+            ctx.frame(params, d_in[st], g, u["flat"], u["sat"], u["m"], u["c"], idx=u["i"], stream=st)
+            lib.vp_copy_d2h(ctx.h, st, C.c_void_p(h_m[st].data_ptr()), C.c_void_p(u["m"].data_ptr()), C.c_size_t(g * 22 * mm))
+            lib.vp_copy_d2h(ctx.h, st, C.c_void_p(h_c[st].data_ptr()), C.c_void_p(u["c"].data_ptr()), C.c_size_t(g * 12))
+        kk = [0]
+
+        def pcie_step():
+            pcie(kk[0])
+            kk[0] += 1
+        out["frames_per_s_pcie_inclusive"] = round(rate(pcie_step, 40, g), 1)
+        out["note"] = "measured after the timed region on the same resident frames (PCIe figure: host-pinned frames copied in, records copied out); none of these is `value`"
+    finally:
+        ctx.close()
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not imported torch nor touched a
     GPU), relay rank 0's stdout, wait for all, exit with the worst return code."""
@@ -238,6 +313,8 @@ def main():
                     "slot, host threads, overlapped with the next step's kernels) and gather the encoded SSL_WrapperPackets instead of the blob records. Off by default: "
                     "the headline metric is the GPU hot path.")
     ap.add_argument("--detect-threads", type=int, default=0, help="host threads of the CPU stage (0 = this rank's share of the cores)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements taken after the headline region (batch sweep, single-frame latency, "
+                    "streams in flight, PCIe-inclusive rate); they run at N = 1 only and never enter `value`")
     ap.add_argument("--opencl-probe", action="store_true", help="print the OpenCL platform / device report as JSON and exit (used as a child process)")
     args = ap.parse_args()
     if args.opencl_probe:
@@ -452,6 +529,8 @@ def main():
                 out["detect"]["gathered_packets"] = sum(1 for r in allp for p in r if p)
                 assert allp[0] == mine
             out["config"]["sharding"] = f"{world} x {B} independent feeds" + (f", {coll} all-gather of SSL_WrapperPackets per step" if dist else "")
+        if world == 1 and not args.no_extras and det is None:
+            out["extras"] = extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, counter, idx, B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, opencl)
             out["opencl"] = opencl

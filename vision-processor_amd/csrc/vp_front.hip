@@ -717,56 +717,65 @@ __global__ __launch_bounds__(256) void k_resample_staged_bgr(const uint8_t* __re
 	}
 }
 
+// Unstaged coordinate-map kernel (odd quad widths, single frames, sensors the staged kernels do not take).  A thread owns MAPPED_ROWS
+// vertically adjacent flat pixels: one flat pixel per thread made this a 49 152-wavefront launch for one 2048x1536 frame, bound by the
+// rate at which wavefronts can be started (~11 us of a 22 us kernel).
+constexpr int MAPPED_ROWS = 4;
 template<int LAYOUT, int MODE>
 __global__ __launch_bounds__(256) void k_resample_mapped(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch) {
 	// 1-D grid, XCD-aware (vp_xcd_remap): consecutive logical ids walk along x, then y, then the frame group
-	const unsigned nbx = (unsigned)(fw + 63) / 64, nby = (unsigned)(fh + 3) / 4;
+	const unsigned nbx = (unsigned)(fw + 63) / 64, nby = (unsigned)(fh + 4 * MAPPED_ROWS - 1) / (4 * MAPPED_ROWS);
 	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
 	const unsigned bz = lb / (nbx * nby), brem = lb - bz * nbx * nby;
 	const int gx = (int)(brem % nbx) * 64 + threadIdx.x;
-	const int gy = (int)(brem / nbx) * 4 + threadIdx.y;
-	const bool valid = gx < fw && gy < fh;
-	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
-	const float px = pos.x, py = pos.y;
 	const int f0 = (int)bz * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
-	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)min(gy, fh - 1) * fw + min(gx, fw - 1);
 	const size_t npx = (size_t)fw * fh;
-	if(LAYOUT != VP_LAYOUT_BGR && MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
-		const Bayer4Geom g = bayer4_geom(px, py, qw, qh);
-		if(!valid) return;
+	if(gx >= fw) return;
+	float2 posr[MAPPED_ROWS]; // all rows' coordinates requested before the first one is used
+#pragma unroll
+	for(int rr = 0; rr < MAPPED_ROWS; rr++) posr[rr] = map[(size_t)min(((int)(brem / nbx) * MAPPED_ROWS + rr) * 4 + (int)threadIdx.y, fh - 1) * fw + gx];
+#pragma unroll
+	for(int rr = 0; rr < MAPPED_ROWS; rr++) {
+		const int gy = ((int)(brem / nbx) * MAPPED_ROWS + rr) * 4 + threadIdx.y;
+		if(gy >= fh) break;
+		const float2 pos = posr[rr];
+		const float px = pos.x, py = pos.y;
+		uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)gy * fw + gx;
+		if(LAYOUT != VP_LAYOUT_BGR && MODE == VP_SAMPLER_BILINEAR_RTZ && qw >= 4) {
+			const Bayer4Geom g = bayer4_geom(px, py, qw, qh);
 #pragma unroll 2
+			for(int f = f0; f < f1; f++) {
+				uint32_t p[4];
+				bayer4_eval(raw + (size_t)f * src_frame_bytes, g, p);
+				const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+				out[(size_t)f * npx] = px4;
+				emit_strip(strips, f, gx, gy, px4);
+			}
+			continue;
+		}
 		for(int f = f0; f < f1; f++) {
-			uint32_t p[4];
-			bayer4_eval(raw + (size_t)f * src_frame_bytes, g, p);
-			const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
+			Src s;
+			s.raw = raw + (size_t)f * src_frame_bytes;
+			s.p[0] = s.p[1] = s.p[2] = s.p[3] = nullptr;
+			uint32_t r, g, b;
+			if(LAYOUT == VP_LAYOUT_BGR) {
+				r = sample<LAYOUT, MODE, true>(s, 2, px, py, qw, qh);
+				g = sample<LAYOUT, MODE, true>(s, 1, px, py, qw, qh);
+				b = sample<LAYOUT, MODE, true>(s, 0, px, py, qw, qh);
+			} else if(LAYOUT == VP_LAYOUT_RGGB) {
+				r = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh);
+				g = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh) / 2;
+				b = sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh);
+			} else {
+				r = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh);
+				g = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh) / 2;
+				b = sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh);
+			}
+			const uint32_t px4 = drgb_pack(r, g, b);
 			out[(size_t)f * npx] = px4;
 			emit_strip(strips, f, gx, gy, px4);
 		}
-		return;
-	}
-	if(!valid) return;
-	for(int f = f0; f < f1; f++) {
-		Src s;
-		s.raw = raw + (size_t)f * src_frame_bytes;
-		s.p[0] = s.p[1] = s.p[2] = s.p[3] = nullptr;
-		uint32_t r, g, b;
-		if(LAYOUT == VP_LAYOUT_BGR) {
-			r = sample<LAYOUT, MODE, true>(s, 2, px, py, qw, qh);
-			g = sample<LAYOUT, MODE, true>(s, 1, px, py, qw, qh);
-			b = sample<LAYOUT, MODE, true>(s, 0, px, py, qw, qh);
-		} else if(LAYOUT == VP_LAYOUT_RGGB) {
-			r = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh);
-			g = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh) / 2;
-			b = sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh);
-		} else {
-			r = sample<LAYOUT, MODE, true>(s, 1, px - 0.25f, py + 0.25f, qw, qh);
-			g = sample<LAYOUT, MODE, true>(s, 0, px + 0.25f, py + 0.25f, qw, qh) / 2 + sample<LAYOUT, MODE, true>(s, 3, px - 0.25f, py - 0.25f, qw, qh) / 2;
-			b = sample<LAYOUT, MODE, true>(s, 2, px + 0.25f, py - 0.25f, qw, qh);
-		}
-		const uint32_t px4 = drgb_pack(r, g, b);
-		out[(size_t)f * npx] = px4;
-		emit_strip(strips, f, gx, gy, px4);
 	}
 }
 
@@ -808,7 +817,7 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, "raw2quad+resampling");
 	const size_t q = (size_t)qw * qh, frame_bytes = layout == VP_LAYOUT_BGR ? 3 * q : 4 * q;
-	const dim3 grid(vp_div_up(fw, 64) * vp_div_up(fh, 4) * vp_div_up(batch, RESAMPLE_FPT)), block(64, 4);
+	const dim3 grid(vp_div_up(fw, 64) * vp_div_up(fh, 4 * MAPPED_ROWS) * vp_div_up(batch, RESAMPLE_FPT)), block(64, 4); // k_resample_mapped
 	hipStream_t s = ctx->streams[stream];
 	const float2* m2 = reinterpret_cast<const float2*>(map);
 	// staged kernel: Bayer + BILINEAR_RTZ with dword-aligned sensor rows; a frame group's spans must fit the 32-bit buffer offsets

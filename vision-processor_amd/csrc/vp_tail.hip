@@ -242,6 +242,8 @@ __device__ __forceinline__ void frame_arrive_and_sort(int32_t* done /* this fram
 __device__ __forceinline__ void emit_record(const uint32_t* __restrict__ f, int w, int h, int px, int py, float v, float nx, float qx, float ny, float qy,
 		float min_score, int radius, int max_matches, int32_t* counter /* frame's [3] */, uint8_t* rec_work, uint32_t* idx_work, int lane) {
 	uint32_t color[3];
+	const uint32_t pix = (uint32_t)(py * w + px);
+	const uint32_t center = f[pix]; // requested together with the disc's pixels, not behind the atomic below
 	const float score = disc_score_wave(f, w, h, px, py, radius, v, color);
 	if(lane == 0) {
 		if(score < min_score) { // :79-82 (NaN is kept)
@@ -251,8 +253,7 @@ __device__ __forceinline__ void emit_record(const uint32_t* __restrict__ f, int 
 			if(i < max_matches) {                   // :88-89
 				const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
 				const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
-				const uint32_t pix = (uint32_t)(py * w + px);
-				store_match(rec_work + (size_t)i * 22, mx, my, color, f[pix], v, score);
+				store_match(rec_work + (size_t)i * 22, mx, my, color, center, v, score);
 				__hip_atomic_store((gu32_t*)(idx_work + i), pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
