@@ -6,9 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/cfg5
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export VP_CFG=cfg5_4096x3072_rggb VP_TWOPASS=1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/tools/satbench.py 16 0 > $O/stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 $R/tools/satbench.py 16 0 > $O/fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 $R/tools/satbench.py 16 0 > $O/write.log 2>&1
-grep -h "GB/s algorithmic" $O/stats.log
+for v in tiled twopass; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$v -o s -- python3 $R/tools/stagebench.py sat 16 --cfg cfg5_4096x3072_rggb --sat $v > $O/stats_$v.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$v -o p -- python3 $R/tools/stagebench.py sat 16 --cfg cfg5_4096x3072_rggb --sat $v --iters 2 > $O/fetch_$v.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$v -o p -- python3 $R/tools/stagebench.py sat 16 --cfg cfg5_4096x3072_rggb --sat $v --iters 2 > $O/write_$v.log 2>&1
+  grep -h "GB/s algorithmic" $O/stats_$v.log
+done
 echo done

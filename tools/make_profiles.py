@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 shutil.copy(os.path.join(P, "stats", "s_kernel_stats.csv"), os.path.join(OUT, f"{tag}_kernel_stats.csv"))
 bench = json.loads(open(os.path.join(P, "bench_default.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(OUT, f"{tag}_bench_n1.json"), "w"), indent=1)
@@ -39,7 +39,7 @@ def short(k):
 fetch, write = pmc("pmc_fetch"), pmc("pmc_write")
 kernels = {}
 for k in fetch:
-    if not any(t in k for t in ("k_resample_staged", "k_sat_fast", "k_circle_detect", "k_emit")):
+    if not any(t in k for t in ("k_resample_staged", "k_sat_fast", "k_circle_walk", "k_emit")):
         continue
     f_kb, w_kb = fetch[k], write.get(k, 0.0)
     kernels[short(k)] = {"FETCH_SIZE_KB_per_launch": round(f_kb, 1), "WRITE_SIZE_KB_per_launch": round(w_kb, 1),
@@ -63,7 +63,9 @@ if "history" in old:
     doc["history"] = old["history"]
 json.dump(doc, open(os.path.join(OUT, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 key = f"{bench['config']['workload']}/b{frames}/tiled"
-json.dump({key: {"hbm_bytes_per_launch": sat["hbm_bytes_per_launch_corrected"], "source": f"profiles/{tag}_pmc_hbm.json"}},
+sys.path.insert(0, ROOT)
+import bench as bench_mod  # the hash of the kernel sources the traffic figure belongs to (bench.py emits null on a mismatch)
+json.dump({key: {"hbm_bytes_per_launch": sat["hbm_bytes_per_launch_corrected"], "source": f"profiles/{tag}_pmc_hbm.json", "kernels_hash": bench_mod.kernels_hash()}},
           open(os.path.join(OUT, "hbm_traffic.json"), "w"), indent=1)
 sweep = {}
 for b in (1, 8, 32, 64, 128, 256):
@@ -72,9 +74,9 @@ for b in (1, 8, 32, 64, 128, 256):
 tw = json.loads(open(os.path.join(P, "bench_twopass.json")).read())
 extra = {"batch_sweep": sweep,
          "twopass_at_128": {"frames_per_s": tw["value"], "sat_launch_ms": tw["roofline"]["launch_ms"], "sat_frac": tw["roofline"]["frac"]},
-         "satbench_cfg5": open(os.path.join(P, "satbench_cfg5.txt")).read().strip().splitlines()[-2:],
-         "satbench_cfg1": open(os.path.join(P, "satbench_cfg1.txt")).read().strip().splitlines()[-2:],
-         "latency": [ln for ln in open(os.path.join(P, "latency.txt")).read().strip().splitlines() if "frames/s" in ln]}
+         "stagebench_cfg5": open(os.path.join(P, "stage_cfg5.txt")).read().strip().splitlines(),
+         "stagebench_cfg1": open(os.path.join(P, "stage_cfg1.txt")).read().strip().splitlines(),
+         "extras_of_the_bench_line": bench.get("extras")}
 json.dump(extra, open(os.path.join(OUT, f"{tag}_sweeps.json"), "w"), indent=1)
 print(json.dumps(doc["kernels"], indent=1))
 print(doc["reading"])

@@ -1,0 +1,46 @@
+"""One stage of the hot path alone, timed with stream events (tools only).
+usage: stagebench.py STAGE BATCH [--cfg NAME] [--sat tiled|twopass] [--iters N]     STAGE = resample | sat | tail | frame
+Prints  "<stage> <cfg> B=<batch> sat=<variant>: median <us> us/launch, <GB/s> GB/s algorithmic"  (algorithmic bytes: DESIGN.md section 3)."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from _vp_pkg import load
+ap = argparse.ArgumentParser()
+ap.add_argument("stage"); ap.add_argument("batch", type=int)
+ap.add_argument("--cfg", default="cfg2_2048x1536_rggb"); ap.add_argument("--sat", default="tiled"); ap.add_argument("--iters", type=int, default=10)
+a = ap.parse_args()
+vp = load(); capi = vp.load_capi()
+cfg = vp.configs.ALL[a.cfg]; B = a.batch; mm = cfg.max_matches
+variant = capi.SAT_TILED if a.sat == "tiled" else capi.SAT_TWOPASS
+ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+raw4 = torch.from_numpy(np.stack([cfg.synth(i) for i in range(4)])).cuda()
+raw = raw4.repeat((B + 3) // 4, *([1] * (raw4.dim() - 1)))[:B].contiguous()
+d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
+         matches=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"), counter=torch.zeros((B, 3), dtype=torch.int32, device="cuda"))
+p = capi.frame_params(cfg, sat_variant=variant)
+ctx.frame(p, raw, B, **d); ctx.sync()
+d_map = torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda")
+ctx.resample_map(cfg.model(), cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, d_map)
+strips = None
+nb = ctx.halo_strip_bytes(cfg.fw, cfg.fh, cfg.grad_offset)
+if nb:
+    strips = torch.zeros((B, nb // 4), dtype=torch.int32, device="cuda")
+    ctx.halo_strips(d["flat"], cfg.fw, cfg.fh, cfg.grad_offset, B, strips)
+def fn():
+    if a.stage == "resample": ctx.resample_raw_mapped(raw, cfg.layout, cfg.qw, cfg.qh, d_map, cfg.sampler_mode, cfg.fw, cfg.fh, B, d["flat"])
+    elif a.stage == "sat":
+        if strips is not None and variant == capi.SAT_TILED: ctx.graddot_sat_strips(d["flat"], strips, cfg.fw, cfg.fh, cfg.grad_offset, B, variant, d["sat"])
+        else: ctx.graddot_sat(d["flat"], cfg.fw, cfg.fh, cfg.grad_offset, B, variant, d["sat"])
+    elif a.stage == "tail": ctx.blobcenter_list(d["flat"], d["sat"], cfg.fw, cfg.fh, B, cfg.circle_radius, cfg.circ_threshold, cfg.min_score, cfg.list_radius, mm, capi.ORDER_RASTER, d["matches"], d["idx"], d["counter"])
+    else: ctx.frame(p, raw, B, **d)
+ts = []
+for rnd in range(7):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    if rnd: ts.append(e0.elapsed_time(e1) / a.iters * 1000)
+ctx.sync()
+per_px = {"resample": 1 + 4, "sat": 8, "tail": 4, "frame": 17}[a.stage]  # algorithmic bytes per flat pixel: raw 1 + flat 4 | flat 4 + SAT 4 | SAT 4 | raw 1 + flat 4+4 + SAT 4+4
+med = float(np.median(ts))
+print(f"{a.stage} {cfg.name} B={B} sat={a.sat}: median {med:.1f} us/launch (min {min(ts):.1f}), {med / B:.2f} us/frame, {per_px * cfg.n_flat * B / med / 1e3:.0f} GB/s algorithmic", flush=True)
