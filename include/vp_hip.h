@@ -44,8 +44,11 @@ typedef enum { VP_SAMPLER_NEAREST = 0, VP_SAMPLER_BILINEAR_RTZ = 1 } VpSamplerMo
 /* Summed-area-table implementations.  All produce the same int32 (wrap-around) table; box sums taken from it are
  * exact, and equal the reference's binary32 SAT whenever max|SAT| < 2^24.
  *   TILED    : single pass, LDS-tiled local scans + decoupled look-back of tile carries (8 B/px HBM traffic)
- *   TWOPASS  : global row pass then column pass ("global-recursive" comparison variant, 16 B/px) */
-typedef enum { VP_SAT_TILED = 0, VP_SAT_TWOPASS = 1 } VpSatVariant;
+ *   TWOPASS  : global row pass then column pass ("global-recursive" comparison variant, 16 B/px)
+ *   LOCAL    : vp_frame / vp_flat_bloblist only -- no global table at all: gradientDot, a strip-local table, circle and blobList in ONE kernel that
+ *              reads flat once (the reference keeps its SAT private to rgba2blobCenter, Resources.cpp:155-163).  VpFrameBuffers.sat, .graddot
+ *              and .blobcenter must be NULL.  Same blob list, bit for bit; TILED stays the default and the pass the roofline is quoted on. */
+typedef enum { VP_SAT_TILED = 0, VP_SAT_TWOPASS = 1, VP_SAT_LOCAL = 2 } VpSatVariant;
 
 /* Order of the blob list.  ATOMIC = append order of the device atomics, as in blobList.cl:87 (run-dependent);
  * RASTER = records sorted by pixel index (deterministic whenever counter[0] <= max_matches). */
@@ -202,6 +205,11 @@ int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* flat, const in
 		int circle_radius, float circ_threshold, float min_score, int list_radius, int max_matches, int order,
 		VpMatch* matches, uint32_t* idx, int32_t* counter, float* blobcenter_out);
 
+/* gradient_dotproduct + sat_horizontal/vertical + circle + matches in one kernel, no global table (VP_SAT_LOCAL).  Supported for the
+ * (circle_radius, grad_offset) pairs a geometry can form with circle radius 2..12; other pairs return VP_ERR_INVALID. */
+int vp_flat_bloblist(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float circ_threshold, float min_score,
+		int list_radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter);
+
 /* matches (blobScore.cl:23-67; compiled at blob_benchmark.cpp:117, launch commented out :154-155): score image. */
 int vp_blobscore(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, int w, int h, int batch,
 		float circ_threshold, int radius, float* score);
@@ -253,7 +261,7 @@ typedef struct {
 
 typedef struct {
 	uint8_t* flat;        /* required: batch x fh x fw x 4 */
-	int32_t* sat;         /* required: batch x fh x fw */
+	int32_t* sat;         /* required: batch x fh x fw (NULL with VP_SAT_LOCAL) */
 	VpMatch* matches;     /* required: batch x max_matches */
 	uint32_t* idx;        /* optional */
 	int32_t* counter;     /* required: batch x 3 */

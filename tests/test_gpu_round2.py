@@ -324,3 +324,99 @@ def test_gather_abi_in_process(env):
         multi.vp_gather_destroy(g)
         for c in ctxs:
             c.close()
+
+
+# ---- VP_SAT_LOCAL: no global table ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,mode,seed", cases.CHAIN_CASES, ids=[cases.chain_case_name(*c) for c in cases.CHAIN_CASES])
+def test_local_table_variant_on_the_goldens(env, cfg, mode, seed):
+    """vp_frame with sat_variant = VP_SAT_LOCAL (buffers.sat = NULL): flat, counters and the sorted records equal the golden vectors, i.e.
+    what the global-table path and the reference-derived fixtures give, bit for bit."""
+    capi, torch = env
+    g = cases.load_golden(cases.chain_case_name(cfg, mode, seed))
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        mm = cfg.max_matches
+        for order in (capi.ORDER_RASTER, capi.ORDER_ATOMIC):
+            for seg in (0, 16, 64):
+                ctx.tune("tail_segment_rows", seg)
+                p = capi.frame_params(cfg, sat_variant=capi.SAT_LOCAL, order=order, sampler_mode=mode)
+                flat = torch.zeros((cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+                m = torch.zeros(mm * 22, dtype=torch.uint8, device="cuda")
+                idx = torch.zeros(mm, dtype=torch.int32, device="cuda")
+                cnt = torch.full((3,), -9, dtype=torch.int32, device="cuda")
+                ctx.frame(p, dev(torch, g["raw"]), 1, flat, None, m, cnt, idx=idx)
+                ctx.sync()
+                assert np.array_equal(flat.cpu().numpy(), g["flat"])
+                c = cnt.cpu().numpy()
+                assert np.array_equal(c, g["counter"]), (order, seg, c, g["counter"])
+                gm, gi = capi.sorted_blobs(m.cpu().numpy(), idx.cpu().numpy().view(np.uint32), c, mm)
+                wm = np.frombuffer(np.ascontiguousarray(g["matches"]).tobytes(), capi.MATCH_DTYPE)
+                assert np.array_equal(gi, g["idx"]) and gm.tobytes() == wm.tobytes(), (order, seg)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", sorted(cases.flat_cases()))
+def test_local_table_variant_on_the_flat_edge_cases(env, name):
+    """The hand-made flat images (blobs on every border, plateaus, uniform discs with infinite score, list overflow, the 2^24-guard violation)
+    through vp_flat_bloblist, where the (r, o) pair has a kernel."""
+    capi, torch = env
+    case = cases.flat_cases()[name]
+    g = cases.load_golden(name)
+    if "blobcenter" in case or case["o"] < 1:
+        pytest.skip("case starts from a hand-made blobCenter image / o = 0: no gradientDot to form")
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        flat = case["flat"]
+        h, w = flat.shape[:2]
+        mm = case["max_matches"]
+        m = torch.zeros(mm * 22, dtype=torch.uint8, device="cuda")
+        idx = torch.zeros(mm, dtype=torch.int32, device="cuda")
+        cnt = torch.full((3,), -9, dtype=torch.int32, device="cuda")
+        try:
+            ctx.flat_bloblist(dev(torch, flat), w, h, 1, case["o"], case["r"], case["thr"], case["min_score"], case["R"], mm, capi.ORDER_RASTER, m, idx, cnt)
+        except capi.VpError as e:
+            assert e.code == -1 and "no kernel for circle radius" in str(e)  # a hand-made (r, o) pair no geometry forms: refused loudly
+            pytest.skip(str(e))
+        ctx.sync()
+        c = cnt.cpu().numpy()
+        assert np.array_equal(c, g["counter"]), (c, g["counter"])
+        if int(c[0]) <= mm:
+            gm, gi = capi.sorted_blobs(m.cpu().numpy(), idx.cpu().numpy().view(np.uint32), c, mm)
+            wm = np.frombuffer(np.ascontiguousarray(g["matches"]).tobytes(), capi.MATCH_DTYPE)
+            assert np.array_equal(gi, g["idx"]) and gm.tobytes() == wm.tobytes()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.CFG1, cfgs.CFG2, cfgs.CFG5], ids=lambda c: c.name)
+def test_local_table_variant_equals_the_global_table_path(env, cfg):
+    """Batches at the mid and the BASELINE sizes (2048x1536 r = 5 o = 2, 4096x3072 r = 9 o = 3, 640x480 BGR r = 4 o = 1): VP_SAT_LOCAL and
+    VP_SAT_TILED produce the same counters and the same records in the same (RASTER) order, byte for byte."""
+    capi, torch = env
+    B = 3 if cfg.n_flat > 4e6 else 5
+    mm = cfg.max_matches
+    raws = dev(torch, np.stack([cfg.synth(4000 + i) for i in range(B)]))
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        outs = []
+        for variant in (capi.SAT_TILED, capi.SAT_LOCAL):
+            p = capi.frame_params(cfg, sat_variant=variant, order=capi.ORDER_RASTER)
+            flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+            sat = torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda") if variant == capi.SAT_TILED else None
+            m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda")
+            idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+            cnt = torch.full((B, 3), -9, dtype=torch.int32, device="cuda")
+            for rep in range(2):
+                ctx.frame(p, raws, B, flat, sat, m, cnt, idx=idx)
+            ctx.sync()
+            outs.append((flat.cpu().numpy(), m.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()))
+        a, b = outs
+        assert np.array_equal(a[3], b[3]), (a[3], b[3])
+        assert int(a[3][:, 0].min()) > 10
+        assert np.array_equal(a[0], b[0])
+        for i in range(B):
+            nrec = min(int(a[3][i, 0]), mm)
+            assert np.array_equal(a[2][i, :nrec], b[2][i, :nrec]) and a[1][i, :nrec * 22].tobytes() == b[1][i, :nrec * 22].tobytes(), i
+    finally:
+        ctx.close()

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("VP_HIP_LIB") or os.path.join(HERE, "libvp_hip.so")  # VP_HIP_LIB: A/B builds side by side (tools only)
 
 VP_OK = 0
-SAT_TILED, SAT_TWOPASS = 0, 1
+SAT_TILED, SAT_TWOPASS, SAT_LOCAL = 0, 1, 2
 ORDER_ATOMIC, ORDER_RASTER = 0, 1
 
 MATCH_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("color", "u1", (3,)), ("center", "u1", (3,)), ("circ", "<f4"), ("score", "<f4")])
@@ -248,6 +248,10 @@ class Context:
     def blobcenter_list(self, flat, sat, w, h, batch, circle_radius, thr, min_score, list_radius, max_matches, order, matches, idx, counter, blobcenter_out=None, stream=0):
         self._ck(self.l.vp_blobcenter_list(self.h, stream, _ptr(flat), _ptr(sat), int(w), int(h), int(batch), int(circle_radius), C.c_float(thr), C.c_float(min_score),
                                            int(list_radius), int(max_matches), int(order), _ptr(matches), _ptr(idx), _ptr(counter), _ptr(blobcenter_out)))
+
+    def flat_bloblist(self, flat, w, h, batch, grad_offset, circle_radius, thr, min_score, list_radius, max_matches, order, matches, idx, counter, stream=0):
+        self._ck(self.l.vp_flat_bloblist(self.h, stream, _ptr(flat), int(w), int(h), int(batch), int(grad_offset), int(circle_radius), C.c_float(thr), C.c_float(min_score),
+                                         int(list_radius), int(max_matches), int(order), _ptr(matches), _ptr(idx), _ptr(counter)))
 
     def blobscore(self, flat, blobcenter, w, h, batch, thr, radius, score, stream=0):
         self._ck(self.l.vp_blobscore(self.h, stream, _ptr(flat), _ptr(blobcenter), int(w), int(h), int(batch), C.c_float(thr), int(radius), _ptr(score)))

@@ -189,6 +189,37 @@ __device__ __forceinline__ int vp_wave_scan_incl(int v) {
 	return v;
 }
 
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// inclusive wave-64 prefix sum in 6 DPP adds (row_shr 1,2,4,8 inside each 16-lane row, then row_bcast 15 / 31)
+__device__ __forceinline__ int scan_incl_dpp(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+	return v;
+}
+
+// sum over channels of (xp - xn) * (yp - yn) on RGBA8 taps (gradientDot.cl:25-29).  Alpha is 255 on every tap: its difference
+// is 0 and is left out.  The byte differences are formed by SDWA subtractions that read one byte of each operand and write
+// one 16-bit half of the result (v_sub_u16_sdwa ... src_sel:BYTE_n dst_sel:WORD_m): (R, B) packed in one register, G in
+// another, then two 2-way 16-bit dot products.  8 VALU instructions per pixel; the mask / shift / v_pk_sub_i16 form took 14
+// and this phase is what bounds the kernel (measured: ~60 % of the pass is VALU issue time).
+__device__ __forceinline__ int grad_dot_pk(uint32_t xp, uint32_t xn, uint32_t yp, uint32_t yn) {
+	uint32_t gx_rb, gx_g, gy_rb, gy_g;
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(gx_rb) : "v"(xp), "v"(xn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(gx_rb) : "v"(xp), "v"(xn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(gx_g) : "v"(xp), "v"(xn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(gy_rb) : "v"(yp), "v"(yn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(gy_rb) : "v"(yp), "v"(yn));
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(gy_g) : "v"(yp), "v"(yn));
+	int acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, gx_rb), __builtin_bit_cast(short2v, gy_rb), 0, false);
+	acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, gx_g), __builtin_bit_cast(short2v, gy_g), acc, false);
+	return acc;
+}
+
 __device__ __forceinline__ int vp_wave_sum(int v) {
 #pragma unroll
 	for(int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);

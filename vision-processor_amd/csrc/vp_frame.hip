@@ -13,13 +13,17 @@ int vp_resample_impl(VpContext* ctx, int stream, const uint8_t* src, bool from_r
 		float max_robot_height, float field_scale, float off_x, float off_y, int sampler_mode, int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips);
 int vp_sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name, const uint32_t* strips,
 		int32_t* zero3, bool* zeroed);
+int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float thr, float min_score, int radius,
+		int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter);
 int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
 		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed);
 
 extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_REQUIRE(p && raw && b, "vp_frame: null pointer");
-	VP_REQUIRE(b->flat && b->sat && b->matches && b->counter, "vp_frame: flat, sat, matches and counter buffers are required");
+	const bool local = p->sat_variant == VP_SAT_LOCAL;
+	VP_REQUIRE(b->flat && (b->sat || local) && b->matches && b->counter, "vp_frame: flat, sat, matches and counter buffers are required");
+	VP_REQUIRE(!local || (!b->sat && !b->graddot && !b->blobcenter), "vp_frame: VP_SAT_LOCAL builds no global table: sat, graddot and blobcenter must be NULL");
 	// halo strips for the single-pass SAT: written by whichever resampling kernel produces flat (6 % of flat, saves the SAT
 	// kernel a 128-byte line per row and side of every tile)
 	VpStrips strips = vp_make_strips(nullptr, 64, 1, 1);
@@ -54,7 +58,12 @@ extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, cons
 	VP_REQUIRE(p->fw > 0 && p->fh > 0 && batch > 0 && batch <= 65535 && p->list_radius >= 0 && p->circle_radius >= 0 && p->max_matches > 0 && (size_t)p->fw * p->fh < (size_t(1) << 31), "vp_frame: bad shape");
 	VP_REQUIRE(p->order == VP_ORDER_ATOMIC || p->order == VP_ORDER_RASTER, "vp_frame: bad order");
 	VP_REQUIRE((reinterpret_cast<uintptr_t>(b->matches) & 1) == 0, "vp_frame: matches must be 2-byte aligned");
-	// four launches per call: [raw2quad+resampling] -> [gradientDot+SAT, which also clears the list counters] -> [circle+detect] -> [emit (+ sort)]
+	if(local) { // resampling -> [gradientDot + local table + circle + blobList]
+		VpStageTimer t(ctx, stream, "gradientDot+satBlobCenter+blobList (local)");
+		return vp_flat_bloblist_impl(ctx, stream, b->flat, p->fw, p->fh, batch, p->grad_offset, p->circle_radius, p->circ_threshold, p->min_score, p->list_radius, p->max_matches, p->order,
+				b->matches, b->idx, b->counter);
+	}
+	// three launches per call: [raw2quad+resampling] -> [gradientDot+SAT, which also clears the list counters] -> [circle+detect] -> [emit (+ sort)]
 	bool zeroed = false;
 	VP_TRY(vp_sat_common(ctx, stream, b->flat, true, p->fw, p->fh, p->grad_offset, batch, p->sat_variant, b->sat, b->graddot, "gradientDot+sat", strips.base, b->counter, &zeroed));
 	VpStageTimer t(ctx, stream, "satBlobCenter+blobList");

@@ -466,6 +466,178 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 }
 
 
+// ---------------------------------------------------------------- VP_SAT_LOCAL: gradientDot + circle + blobList from flat -------------
+// The reference keeps its SAT private to rgba2blobCenter (Resources.cpp:155-163): nothing outside reads it.  Box sums with r <= 12 only need
+// a table that is consistent inside the box, so the walker above can carry its OWN strip-local table instead of reading the global one:
+//   a lane owns column x and walks down; per row it loads flat(x, y+o) (one dword), forms gradientDot(x, y) from the flat values of the lanes
+//   x +- o (ds_bpermute) and of its own column o rows up / down (register window), prefix-sums gradientDot across the wavefront (6 DPP adds:
+//   the row of a SAT whose origin is the strip's first column) and adds it to its running column sum: S(x, y), exact in wrapping int32.
+// Everything downstream is the walker: row differences D1 / D2 from the lanes x +- 1, x +- r, the four quadrant sums, blobCenter, the peak
+// test, record emission, the sort by the frame's last workgroup.  HBM traffic per frame: flat once (+ strip overlap) instead of flat + the
+// SAT written and read back: 53.5 MB -> ~31 MB at 2048x1536, and two launches become one.  Bit-identical to the global-table path: a box sum
+// is a difference of four table entries, and any origin gives the same difference (mod 2^32).
+// Clamp-to-edge: image columns < 0 have no gradientDot (their lanes add 0) and every tap address is clamped to the lane of column 0 / w-1;
+// rows > h-1 add nothing, so the table keeps its last row (= the clamped read); rows < 0 take D(0) (the windows are filled when row 0 is formed).
+// A wavefront yields 62 - 2(r + o) columns.
+template<int RT, int OT>
+__global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ flat, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work,
+		uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame, float thr, float min_score, int list_radius, int max_matches,
+		int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+	__shared__ uint32_t tile[256];
+	__shared__ int s_last;
+	constexpr int R = RT, O = OT, PF = 4, WFL = ((2 * O + 1 + 3) / 4) * 4, WL = ((2 * R + 1 + WFL - 1) / WFL) * WFL, USE = 62 - 2 * (R + O);
+	static_assert(USE >= 16 && WL % WFL == 0 && WFL % PF == 0, "window geometry");
+	const int lane = threadIdx.x & 63;
+	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
+	const int z = (int)(lb / (unsigned)wgs_per_frame);
+	const int item = __builtin_amdgcn_readfirstlane((int)(lb - (unsigned)z * (unsigned)wgs_per_frame) * 4 + (int)(threadIdx.x >> 6));
+	const size_t n = (size_t)w * h;
+	if(item < items_per_frame) { // wave-uniform: the padding wavefronts only take part in the arrival below
+	const int strip = item % strips_x, seg = item / strips_x;
+	const int ya = seg * seg_h, yb = min(h, ya + seg_h);
+	const int x0 = strip * USE - (R + O + 1), x = x0 + lane; // column of lane 0, of this lane
+	const uint32_t oe = 4u * (uint32_t)vp_clampi(x, 0, w - 1);
+	// tap lanes, clamp-to-edge on the column (gradientDot.cl:20, satBlobCenter.cl:20): lane of column clamp(x + d)
+	auto tap = [&](int d) { return 4 * ((vp_clampi(x + d, 0, w - 1) - x0) & 63); };
+	int a_fp = tap(O), a_fn = tap(-O), a_hi = tap(R), a_p1 = tap(1), a_m1 = tap(-1), a_lo = tap(-R);
+	asm volatile("" : "+v"(a_fp), "+v"(a_fn), "+v"(a_hi), "+v"(a_p1), "+v"(a_m1), "+v"(a_lo));
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(flat + z * n), 0, (int)(n * 4), 0x00020000); // host: n * 4 < 2^31
+	const uint32_t row_bytes = (uint32_t)w * 4u;
+	const bool g_ok = lane >= O && lane <= 63 - O && x >= 0 && x < w;      // gradientDot of this lane's column exists (its x +- o taps are in the wavefront)
+	const bool col_ok = lane >= R + O + 1 && lane <= 62 - R - O && x < w;   // this lane reports blobs (x >= 0 for these lanes)
+	const bool x_first = x == 0, x_last = x == w - 1;
+	const float div = (float)(R * R), rcp = 1.0f / div;
+	auto quot = [&](float m) {
+		if(R >= 3 && R <= 10) { // see k_circle_walk
+			const float q0 = m * rcp;
+			return __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
+		}
+		return m / div;
+	};
+	int D1[WL], D2[WL]; // -D1 and D2 of the last WL table rows (k_circle_walk)
+	uint32_t FW[WFL], Pe[PF]; // own-column flat values of the last WFL rows; flat values of the next PF rows in flight
+#pragma unroll
+	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
+#pragma unroll
+	for(int j = 0; j < WFL; j++) FW[j] = 0;
+	float up = 0.f, mid = 0.f;
+	int rej = 0, S = 0; // S: this lane's column of the strip-local table
+	const uint32_t* fz = flat + z * n;
+	// step k loads flat row f = f0 + k, forms gradientDot / the table row t' = f - o (from k = 2o on: table origin row ya-1-r), blobCenter row
+	// t = t' - r (from k = 2o + 2r on: row ya - 1) and tests row y = t - 1
+	const int f0 = ya - 1 - R - O;
+	const int nsteps = 2 * O + 2 * R + (yb - ya) + 2;
+#define VP_FW_ISSUE(SLOT, K) Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)vp_clampi(f0 + (K), 0, h - 1) * row_bytes, 0)
+#pragma unroll
+	for(int p = 0; p < PF; p++) VP_FW_ISSUE(p, p);
+	for(int kb = 0; kb < nsteps; kb += WL) {
+#pragma unroll
+		for(int j = 0; j < WL; j++) {
+			const int k = kb + j;
+			const uint32_t e = Pe[j % PF];
+			VP_FW_ISSUE(j % PF, k + PF);
+			FW[j % WFL] = e;
+			const int tq = f0 + k - O; // table row t'
+			{
+				const uint32_t c = FW[(j - O + 2 * WFL) % WFL], yn = FW[(j - 2 * O + 2 * WFL) % WFL]; // flat(x, t'), flat(x, t' - o); e = flat(x, t' + o)
+				const uint32_t xp = (uint32_t)__builtin_amdgcn_ds_bpermute(a_fp, (int)c), xn = (uint32_t)__builtin_amdgcn_ds_bpermute(a_fn, (int)c);
+				int g = grad_dot_pk(xp, xn, e, yn); // gradientDot.cl:25-29
+				if(!(g_ok && k >= 2 * O && tq >= 0 && tq < h)) g = 0;
+				S += scan_incl_dpp(g);
+			}
+			{
+				const int sa = __builtin_amdgcn_ds_bpermute(a_hi, S), sd = __builtin_amdgcn_ds_bpermute(a_lo, S);
+				const int sb = __builtin_amdgcn_ds_bpermute(a_p1, S), sc = __builtin_amdgcn_ds_bpermute(a_m1, S);
+				D1[j] = (int)((uint32_t)sb - (uint32_t)sa);
+				D2[j] = (int)((uint32_t)sc - (uint32_t)sd);
+			}
+			if(tq == 0) { // rows above the image read row 0 (clamp-to-edge): every window slot of a negative row takes D(0)
+#pragma unroll
+				for(int q = 0; q < WL; q++) {
+					D1[q] = D1[j];
+					D2[q] = D2[j];
+				}
+			}
+			const int jp1 = (j - R + 1 + 2 * WL) % WL, jm1 = (j - R - 1 + 2 * WL) % WL, jmr = (j - 2 * R + 2 * WL) % WL; // table rows t+1, t-1, t-r (row t+r is j)
+			const int pp = (int)((uint32_t)D1[jp1] - (uint32_t)D1[j]), pn = (int)((uint32_t)D1[jm1] - (uint32_t)D1[jmr]);
+			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
+			const float dn = quot((float)min(min(pp, nn), min(pn, np))); // blobCenter(x, t), t = t' - r
+			const int y = tq - R - 1; // the row whose four neighbours are now known
+			if(k >= 2 * O + 2 * R + 2 && y < yb) { // scalar condition
+				const float v = mid;
+				float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); // lane i <- lane i-1
+				float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); // lane i <- lane i+1
+				if(x_first) lf = v;
+				if(x_last) rt = v;
+				const float uv = y == 0 ? v : up, dv = y == h - 1 ? v : dn;
+				const bool above = col_ok && !(v < thr);                   // blobList.cl:39
+				const bool peak = !(lf > v || rt > v || uv > v || dv > v); // :47-52
+				rej += __popcll(__ballot(above && !peak));                 // :53
+				unsigned long long cm = __ballot(above && peak);
+				while(cm != 0) { // wave-uniform: one record per survivor (blobList.cl:57-102)
+					const int b = __ffsll((long long)cm) - 1;
+					cm &= cm - 1;
+					const int px = __builtin_amdgcn_readlane(x, b);
+					const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
+					const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), b)), cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rt), b));
+					const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uv), b)), cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), b));
+					emit_record(fz, w, h, px, y, cv, cl, cr, cu, cd, min_score, list_radius, max_matches, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, lane);
+				}
+			}
+			up = mid;
+			mid = dn;
+		}
+	}
+#undef VP_FW_ISSUE
+	if(rej != 0 && lane == 0) atomicAdd(&counter[3 * z + 2], rej);
+	} // item < items_per_frame
+	frame_arrive_and_sort(done + (size_t)z * ARRIVE_WORDS, (int)(lb - (unsigned)z * (unsigned)wgs_per_frame), wgs_per_frame, nullptr, counter + 3 * z,
+			rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, max_matches, order,
+			rec_sorted + (size_t)z * max_matches * 22, idx_sorted ? idx_sorted + (size_t)z * max_matches : nullptr, tile, &s_last);
+}
+
+// flat -> blob list with no global table (VP_SAT_LOCAL).  (r, o) pairs: every pair ceil(20 / fs), ceil(25 / fs) / 3 can form for r = 2 .. 12.
+int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float thr, float min_score, int radius,
+		int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter) {
+	hipStream_t s = ctx->streams[stream];
+	VP_REQUIRE((size_t)w * h * 4 < 0x7fffffffu, "VP_SAT_LOCAL: frame too large");
+	ListScratch ws;
+	VP_TRY(list_scratch(ctx, stream, batch, max_matches, &ws));
+	k_zero<<<vp_div_up(3 * batch, 256), 256, 0, s>>>(counter, 3 * batch); // main.cpp:283-288
+	VP_TRY(vp_launch_ok("blobList counters"));
+	const bool raster = order == VP_ORDER_RASTER;
+	uint32_t* idx_work = (raster || !idx) ? ws.idx : idx;
+	uint8_t* rec_work = raster ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
+	const int use = 62 - 2 * (circle_radius + grad_offset);
+	VP_REQUIRE(use >= 16, "VP_SAT_LOCAL: circle radius %d + gradient offset %d too large for a wavefront strip", circle_radius, grad_offset);
+	const int strips_x = (int)vp_div_up(w, use);
+	int seg_h = ctx->tune.tail_segment_rows;
+	if(seg_h <= 0) {
+		seg_h = 32;
+		for(int cand_h : {256, 128, 64})
+			if((long long)strips_x * vp_div_up(h, cand_h) * batch >= 8192) {
+				seg_h = cand_h;
+				break;
+			}
+	}
+	const int segs_y = (int)vp_div_up(h, seg_h);
+	const long long ipf = (long long)strips_x * segs_y, wpf = (ipf + 3) / 4;
+	VP_REQUIRE(wpf * batch < (1ll << 31) && ipf < (1ll << 30), "VP_SAT_LOCAL: too many work items");
+	const unsigned grid = (unsigned)(wpf * batch);
+	const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flat);
+	uint8_t* msorted = reinterpret_cast<uint8_t*>(matches);
+	bool launched = false;
+#define VP_FW(R, OO) \
+	if(!launched && circle_radius == R && grad_offset == OO) { \
+		k_flat_walk<R, OO><<<grid, 256, 0, s>>>(f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, min_score, radius, max_matches, order, msorted, idx); \
+		launched = true; \
+	}
+	VP_FW(2, 1) VP_FW(3, 1) VP_FW(4, 1) VP_FW(5, 2) VP_FW(6, 2) VP_FW(7, 2) VP_FW(7, 3) VP_FW(8, 3) VP_FW(9, 3) VP_FW(9, 4) VP_FW(10, 4) VP_FW(11, 4) VP_FW(12, 4)
+#undef VP_FW
+	VP_REQUIRE(launched, "VP_SAT_LOCAL: no kernel for circle radius %d with gradient offset %d (the pairs real geometries form are built: r 2..12 with o = ceil(25 / fs) / 3)", circle_radius, grad_offset);
+	return vp_launch_ok("gradientDot+circle+blobList (local table)");
+}
+
 // Run-time radius fallback (radii outside the specialised range): the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge
 // addressing (satBlobCenter.cl:20, H7), the box-sum image Bx and then blobCenter for the 64x64 tile plus a 1-pixel ring are built in
 // LDS, then thresholded / peak-tested.  Out-of-image ring positions take the value of the clamped position.
@@ -620,6 +792,16 @@ extern "C" int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* fla
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	VpStageTimer t(ctx, stream, "satBlobCenter+blobList");
 	return vp_list_from_blobcenter(ctx, stream, flat, nullptr, sat, circle_radius, blobcenter_out, w, h, batch, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter, false);
+}
+
+extern "C" int vp_flat_bloblist(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float circ_threshold, float min_score,
+		int list_radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_TRY(list_args_ok("vp_flat_bloblist", flat, flat, w, h, batch, list_radius, max_matches, order, matches, counter));
+	VP_REQUIRE(circle_radius >= 0 && grad_offset >= 0, "vp_flat_bloblist: bad radius / offset");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	VpStageTimer t(ctx, stream, "gradientDot+satBlobCenter+blobList (local)");
+	return vp_flat_bloblist_impl(ctx, stream, flat, w, h, batch, grad_offset, circle_radius, circ_threshold, min_score, list_radius, max_matches, order, matches, idx, counter);
 }
 
 // ---------------------------------------------------------------- validation kernels -------------------------------
