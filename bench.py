@@ -173,6 +173,17 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
                 continue
             sweep[str(b)] = round(rate(lambda: ctx.frame(params, d_raw, b, flat, sat, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
         out["frames_per_s_by_frames_per_launch"] = sweep
+        # The optional variant without a global table (sat_variant = VP_SAT_LOCAL: gradientDot + strip-local table + circle + blobList in one
+        # kernel, flat read once, buffers.sat = NULL).  Same blob list bit for bit (tests/test_gpu_round2.py); the headline keeps the SAT pass.
+        p_local = capi.frame_params(cfg, sat_variant=capi.SAT_LOCAL, order=params.order)
+        local = {}
+        for b in (1, 8, 32, B):
+            if b > B:
+                continue
+            local[str(b)] = round(rate(lambda: ctx.frame(p_local, d_raw, b, flat, None, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
+        out["frames_per_s_sat_local_variant"] = local
+        ctx.frame(params, d_raw, B, flat, sat, matches, counter, idx=idx, stream=0)  # leave the default path's outputs in the buffers
+        ctx.sync()
         # one frame, host-synchronised after every frame: latency of the whole hot path
         n = 200
         ctx.sync()
@@ -305,7 +316,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (one launch group)")
     ap.add_argument("--workload", default="cfg2_2048x1536_rggb")
-    ap.add_argument("--sat", default="tiled", choices=["tiled", "twopass"])
+    ap.add_argument("--sat", default="tiled", choices=["tiled", "twopass", "local"], help="tiled = the single-pass SAT the roofline is quoted on (default); twopass = global-recursive comparison; "
+                    "local = optional variant without a global table (one fused kernel after resampling)")
     ap.add_argument("--order", default="raster", choices=["raster", "atomic"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bounded CPU sample, per baseline (reference kernels and port)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -356,7 +368,7 @@ def main():
     cfg = vp.configs.ALL[args.workload]
     B, mm = args.batch, cfg.max_matches
     ctx = capi.Context(local_rank, stream_ptr=torch.cuda.current_stream().cuda_stream)
-    params = capi.frame_params(cfg, sat_variant=capi.SAT_TILED if args.sat == "tiled" else capi.SAT_TWOPASS,
+    params = capi.frame_params(cfg, sat_variant={"tiled": capi.SAT_TILED, "twopass": capi.SAT_TWOPASS, "local": capi.SAT_LOCAL}[args.sat],
                                order=capi.ORDER_RASTER if args.order == "raster" else capi.ORDER_ATOMIC)
 
     # synthetic feeds: distinct seeds per rank and frame, uploaded once (inputs resident in HBM before the timed region)
@@ -364,7 +376,7 @@ def main():
     raws = np.stack([cfg.synth(feeds.feed_seed(rank, i)) for i in range(B)])
     d_raw = torch.from_numpy(raws).cuda()
     flat = torch.empty((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
-    sat = torch.empty((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
+    sat = torch.empty((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda") if args.sat != "local" else None
     # one fixed-size detection record per frame: [counter 3 x i32 | pad 4 | matches mm x 22 | idx mm x u32]
     rec_bytes = feeds.record_bytes(mm)
     record = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]  # double-buffered: the gather of step k overlaps step k+1
@@ -451,7 +463,7 @@ def main():
     ctx.sync()  # raises VP_ERR_TIMEOUT if a bounded look-back wait of the single-pass SAT expired
     # every step runs the same frames: what the timed steps produce must equal what the warm-up produced
     warm_cnt = (det["c"][(step_no[0] - 1) & 1] if det is not None and step_no[0] else counter).cpu().numpy().copy()
-    warm_sat = sat[B - 1, cfg.fh - 1, cfg.fw - 1].item() if args.warmup else None
+    warm_sat = sat[B - 1, cfg.fh - 1, cfg.fw - 1].item() if args.warmup and sat is not None else None
     ctx.events_clear()
     ctx.events_enable(True)
     if dist:
@@ -471,7 +483,7 @@ def main():
     cnt_now = (det["c"][(step_no[0] - 1) & 1] if det is not None else counter).cpu().numpy()
     if args.warmup:
         assert np.array_equal(cnt_now, warm_cnt), "the timed steps' blob counters differ from the warm-up's on identical input"
-        assert sat[B - 1, cfg.fh - 1, cfg.fw - 1].item() == warm_sat, "the timed steps' SAT differs from the warm-up's on identical input"
+        assert sat is None or sat[B - 1, cfg.fh - 1, cfg.fw - 1].item() == warm_sat, "the timed steps' SAT differs from the warm-up's on identical input"
     assert int(cnt_now[:, 0].min()) >= cfg.n_robots * 5, f"fewer blobs than rendered robot discs: {cnt_now[:, 0].min()}"
     stage_ms = {}
     for name, ms in ctx.event_times():
@@ -484,8 +496,10 @@ def main():
     coll = "gloo (one-GPU rehearsal)" if rehearse else "RCCL"
     if rank == 0:
         cnt = cnt_now
-        sat_ms = float(np.mean(stage_ms["gradientDot+sat"]))
-        algo_bytes = 8.0 * cfg.n_flat * B
+        if args.sat == "local":  # no SAT pass exists: the fused kernel reads flat once (4 B/px algorithmic)
+            roof_kernel, sat_ms, algo_bytes = "gradientDot+circle+blobList, strip-local table (reads flat once)", float(np.mean(stage_ms["gradientDot+satBlobCenter+blobList (local)"])), 4.0 * cfg.n_flat * B
+        else:
+            roof_kernel, sat_ms, algo_bytes = "gradientDot+SAT pass", float(np.mean(stage_ms["gradientDot+sat"])), 8.0 * cfg.n_flat * B
         achieved = algo_bytes / (sat_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of this same command (tools/profile_round.sh -> profiles/hbm_traffic.json), valid only
         # for the kernel sources it was measured on: the entry carries their hash, a mismatch gives null
@@ -504,7 +518,7 @@ def main():
                        "circle_radius": cfg.circle_radius, "list_radius": cfg.list_radius, "max_blobs": mm, "sat_variant": args.sat, "list_order": args.order,
                        "sampler": "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (f", {coll} all-gather of detection records per step" if dist else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "gradientDot+SAT pass", "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},
+                         "kernel": roof_kernel, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},
             "stage_ms_per_step": {k: round(float(np.mean(v)), 4) for k, v in stage_ms.items()},
             "blobs_per_frame": float(np.minimum(cnt[:, 0], mm).mean()),
         }
@@ -529,7 +543,7 @@ def main():
                 out["detect"]["gathered_packets"] = sum(1 for r in allp for p in r if p)
                 assert allp[0] == mine
             out["config"]["sharding"] = f"{world} x {B} independent feeds" + (f", {coll} all-gather of SSL_WrapperPackets per step" if dist else "")
-        if world == 1 and not args.no_extras and det is None:
+        if world == 1 and not args.no_extras and det is None and sat is not None:
             out["extras"] = extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, counter, idx, B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, opencl)
