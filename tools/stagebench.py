@@ -7,12 +7,14 @@ import numpy as np, torch
 from _vp_pkg import load
 ap = argparse.ArgumentParser()
 ap.add_argument("stage"); ap.add_argument("batch", type=int)
-ap.add_argument("--cfg", default="cfg2_2048x1536_rggb"); ap.add_argument("--sat", default="tiled"); ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--cfg", default="cfg2_2048x1536_rggb"); ap.add_argument("--sat", default="tiled"); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--tune", action="append", default=[], help="key=value for vp_ctx_tune")
 a = ap.parse_args()
 vp = load(); capi = vp.load_capi()
 cfg = vp.configs.ALL[a.cfg]; B = a.batch; mm = cfg.max_matches
 variant = capi.SAT_TILED if a.sat == "tiled" else capi.SAT_TWOPASS
 ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+for kv in a.tune:
+    ctx.tune(kv.split("=")[0], int(kv.split("=")[1]))
 raw4 = torch.from_numpy(np.stack([cfg.synth(i) for i in range(4)])).cuda()
 raw = raw4.repeat((B + 3) // 4, *([1] * (raw4.dim() - 1)))[:B].contiguous()
 d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
@@ -43,4 +45,4 @@ for rnd in range(7):
 ctx.sync()
 per_px = {"resample": 1 + 4, "sat": 8, "tail": 4, "frame": 17}[a.stage]  # algorithmic bytes per flat pixel: raw 1 + flat 4 | flat 4 + SAT 4 | SAT 4 | raw 1 + flat 4+4 + SAT 4+4
 med = float(np.median(ts))
-print(f"{a.stage} {cfg.name} B={B} sat={a.sat}: median {med:.1f} us/launch (min {min(ts):.1f}), {med / B:.2f} us/frame, {per_px * cfg.n_flat * B / med / 1e3:.0f} GB/s algorithmic", flush=True)
+print(f"{a.stage} {cfg.name} B={B} sat={a.sat} {" ".join(a.tune)}: median {med:.1f} us/launch (min {min(ts):.1f}), {med / B:.2f} us/frame, {per_px * cfg.n_flat * B / med / 1e3:.0f} GB/s algorithmic", flush=True)
