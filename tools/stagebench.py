@@ -45,4 +45,5 @@ for rnd in range(7):
 ctx.sync()
 per_px = {"resample": 1 + 4, "sat": 8, "tail": 4, "frame": 17}[a.stage]  # algorithmic bytes per flat pixel: raw 1 + flat 4 | flat 4 + SAT 4 | SAT 4 | raw 1 + flat 4+4 + SAT 4+4
 med = float(np.median(ts))
-print(f"{a.stage} {cfg.name} B={B} sat={a.sat} {" ".join(a.tune)}: median {med:.1f} us/launch (min {min(ts):.1f}), {med / B:.2f} us/frame, {per_px * cfg.n_flat * B / med / 1e3:.0f} GB/s algorithmic", flush=True)
+tunes = " ".join(a.tune)
+print(f"{a.stage} {cfg.name} B={B} sat={a.sat} {tunes}: median {med:.1f} us/launch (min {min(ts):.1f}), {med / B:.2f} us/frame, {per_px * cfg.n_flat * B / med / 1e3:.0f} GB/s algorithmic", flush=True)
