@@ -87,7 +87,7 @@ const char* vp_last_error(void);
 int vp_device_count(void);
 const char* vp_device_name(VpContext* ctx);
 /* Result-neutral tuning (every value gives bit-identical output; the library reads no environment variable):
- *   "sat_workgroups_per_cu" 2..8 (default 5), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_float_stage" 0 / 1 (default 1),
+ *   "sat_workgroups_per_cu" 2..8 (0 = automatic, the default), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_float_stage" 0 / 1 (default 1),
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic).  Applies to launches issued after the call. */
 int vp_ctx_tune(VpContext* ctx, const char* key, int value);

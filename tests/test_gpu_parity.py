@@ -350,7 +350,7 @@ def test_fast_sat_edge_shapes(gpu, port, shape, o):
                 ctx.graddot_sat(d_flat, w, h, o, B, capi.SAT_TILED, d_sat, d_gd)
             ctx.sync()
         finally:
-            ctx.tune("sat_workgroups_per_cu", 5)
+            ctx.tune("sat_workgroups_per_cu", 0)
         for i in range(B):
             assert np.array_equal(host(d_sat[i]), want_sat[i]), (gen, with_strips, with_gd, i)
             if with_gd:

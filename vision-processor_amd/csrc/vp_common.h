@@ -42,7 +42,7 @@ struct VpImage {
 
 // Result-neutral tuning knobs (vp_ctx_tune): every value gives bit-identical output.  The library reads no environment variable.
 struct VpTuning {
-	int sat_workgroups_per_cu = 5; // resident workgroups per CU of the single-pass SAT (2..8; 5 and 6 have their own register budget)
+	int sat_workgroups_per_cu = 0; // resident workgroups per CU of the single-pass SAT (2..8; 5 and 6 have their own register budget); 0 = 5, and 4 below 64 frames per launch
 	int resample_xcd_bands = -1;   // staged resampling: XCD-contiguous tile bands; -1 = automatic (on for >= 4096 tiles per frame group)
 	int resample_float_stage = 1;  // staged Bayer resampling, BILINEAR_RTZ: box staged as floats (1) or bytes (0)
 	int resample_bgr_staged = 1;   // BGR8 sensors: staged kernel (1) or the generic mapped kernel (0)

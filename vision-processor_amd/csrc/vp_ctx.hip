@@ -105,7 +105,7 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 	VP_REQUIRE(ctx && key, "vp_ctx_tune: null argument");
 	const std::string k(key);
 	if(k == "sat_workgroups_per_cu") {
-		VP_REQUIRE(value >= 2 && value <= 8, "vp_ctx_tune: sat_workgroups_per_cu %d out of range [2,8]", value);
+		VP_REQUIRE(value == 0 || (value >= 2 && value <= 8), "vp_ctx_tune: sat_workgroups_per_cu %d: 0 (automatic) or 2..8", value);
 		ctx->tune.sat_workgroups_per_cu = value;
 	} else if(k == "resample_xcd_bands") {
 		VP_REQUIRE(value >= -1 && value <= 1, "vp_ctx_tune: resample_xcd_bands takes -1 (automatic), 0 or 1");
