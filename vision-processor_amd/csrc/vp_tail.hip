@@ -334,6 +334,74 @@ __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ a, int na) {
 	if(i < na) a[i] = 0;
 }
 
+// blobCenter = min(quadrant sums) / r^2 (satBlobCenter.cl:41) from the integer minimum.  For r = 3..10: m / (r*r), correctly rounded, without
+// the division sequence: q0 = m*rcp, e = fma(-d, q0, m), q = fma(e, rcp, q0) -- exhaustively verified equal to m / d for every float m =
+// (float)n, |n| <= 2^27, d = 9 .. 100 (tools/divcheck.hip); box sums are < 2^25.
+template<int R>
+__device__ __forceinline__ float walk_quot(int m) {
+	const float div = (float)(R * R), f = (float)m;
+	if(R >= 3 && R <= 10) {
+		const float rcp = 1.0f / div, q0 = f * rcp;
+		return __builtin_fmaf(__builtin_fmaf(-div, q0, f), rcp, q0);
+	}
+	return f / div;
+}
+
+// Threshold + peak test + record emission of one image row for the walkers.  The walkers keep the INTEGER quadrant minimum of the last three
+// rows; int -> float conversion and the division by r^2 are both monotonic, so `blobCenter >= threshold` (blobList.cl:39) is the exact integer
+// test m >= m_thr with m_thr = the smallest integer whose quotient is not below the threshold (found by the host by bisection with the same
+// binary32 division).  Only when some lane of the wavefront passes it (a fraction of a per cent of the rows) are the five blobCenter values
+// formed, the neighbours fetched (left / right by DPP wave shifts; outside the image the pixel's own value: `own > own` is false) and the strict
+// '>' peak test of blobList.cl:47-52 made; survivors become records on the spot (blobList.cl:57-102).  All 64 lanes must be active.
+struct WalkEmit {
+	const uint32_t* flat; // this frame
+	int32_t* counter;     // this frame's [3]
+	uint8_t* rec;         // this frame's append-order records
+	uint32_t* idx;
+	float min_score;
+	int list_radius, max_matches;
+};
+template<int R>
+__device__ __forceinline__ void walk_detect(int m_up, int m_mid, int m_dn, bool col_ok, bool x_first, bool x_last, int x, int y, int w, int h, int m_thr, int& rej,
+		const WalkEmit& em, int lane) {
+	const bool above = col_ok && m_mid >= m_thr; // blobList.cl:39
+	if(__ballot(above) == 0) return;              // wave-uniform
+	const float v = walk_quot<R>(m_mid);
+	float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); // wave_shr:1: lane i <- lane i-1
+	float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); // wave_shl:1: lane i <- lane i+1
+	if(x_first) lf = v;
+	if(x_last) rt = v;
+	const float uv = y == 0 ? v : walk_quot<R>(m_up), dv = y == h - 1 ? v : walk_quot<R>(m_dn);
+	const bool peak = !(lf > v || rt > v || uv > v || dv > v); // :47-52, strict '>'
+	rej += __popcll(__ballot(above && !peak));                 // :53 counter[2]++
+	unsigned long long cm = __ballot(above && peak);
+	while(cm != 0) { // wave-uniform: one record per survivor
+		const int b = __ffsll((long long)cm) - 1;
+		cm &= cm - 1;
+		const int px = __builtin_amdgcn_readlane(x, b);
+		const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
+		const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), b)), cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rt), b));
+		const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uv), b)), cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), b));
+		emit_record(em.flat, w, h, px, y, cv, cl, cr, cu, cd, em.min_score, em.list_radius, em.max_matches, em.counter, em.rec, em.idx, lane);
+	}
+}
+
+// smallest integer m with !(quotient(m) < thr), by bisection (host; the same correctly rounded binary32 division the kernels' quotient equals)
+static int walk_threshold(float thr, int r) {
+	if(thr != thr) return INT32_MIN; // `v < NaN` is false for every v: everything passes (blobList.cl:39)
+	const float div = (float)(r * r);
+	auto passes = [&](long long m) { return !((float)(int)m / div < thr); };
+	if(!passes(INT32_MAX)) return INT32_MAX; // (+inf, or beyond every table value: nothing passes short of INT32_MAX itself)
+	long long lo = INT32_MIN, hi = INT32_MAX; // passes(hi) holds
+	if(passes(lo)) return INT32_MIN;
+	while(hi - lo > 1) {
+		const long long mid = lo + (hi - lo) / 2;
+		if(passes(mid)) hi = mid;
+		else lo = mid;
+	}
+	return (int)hi;
+}
+
 // ---------------------------------------------------------------- circle + detect, fused --------------------------------------
 // satBlobCenter.cl:34-42 + the detection half of blobList.cl:37-55 straight from the SAT; blobCenter never reaches memory.
 //
@@ -357,7 +425,7 @@ __global__ __launch_bounds__(256) void k_zero(int32_t* __restrict__ a, int na) {
 template<int RT, bool BCOUT>
 __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, const uint32_t* __restrict__ flat, int32_t* __restrict__ done,
 		int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work, uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame,
-		float thr, float min_score, int list_radius, int max_matches, int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+		float thr, int m_thr, float min_score, int list_radius, int max_matches, int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
 	constexpr int R = RT, PF = 4, WL = ((2 * R + 1 + PF - 1) / PF) * PF, USE = 62 - 2 * R; // USE: image columns a wavefront yields
@@ -380,25 +448,15 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	const uint32_t row_bytes = (uint32_t)w * 4u;
 	const bool col_ok = lane >= R + 1 && lane <= 62 - R && x < w; // (x >= 0 for these lanes)
 	const bool x_first = x == 0, x_last = x == w - 1;
-	const float div = (float)(R * R), rcp = 1.0f / div;
-	auto quot = [&](float m) {
-		if(R >= 3 && R <= 10) {
-			// m / (r*r), correctly rounded, without the division sequence: q0 = m*rcp, e = fma(-d, q0, m), q = fma(e, rcp, q0).  Exhaustively
-			// verified equal to m / d for every float m = (float)n, |n| <= 2^27, d = 9 .. 100 (tools/divcheck.hip); box sums are < 2^25.
-			const float q0 = m * rcp;
-			return __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
-		}
-		return m / div;
-	};
 	// Windows of the last WL >= 2r+1 rows of -D1 / D2, and the raw SAT values of the next PF rows in flight: a row's load is
 	// issued PF steps before it is used (a walk is one dependent chain per lane; without the run-ahead every step would wait a full
 	// memory round trip).  WL is a multiple of PF and the loop is unrolled WL-fold, so every array index below is a constant.
 	int D1[WL], D2[WL], Pe[PF];
 #pragma unroll
 	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
-	float up = 0.f, mid = 0.f; // blobCenter of rows t-2, t-1 while row t is being formed
+	int m_up = 0, m_mid = 0; // integer quadrant minimum (blobCenter * r^2) of rows t-2, t-1 while row t is being formed
 	int rej = 0;
-	const uint32_t* fz = flat + z * n;
+	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
 	const int s0 = ya - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ya - 1 at k = 2r, when the windows are full
 	const int nsteps = 2 * R + (yb - ya) + 2;
 #define VP_WK_ISSUE(SLOT, K)                                                                                                           \
@@ -427,35 +485,13 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 			const int jp1 = (j - R + 1 + 2 * WL) % WL, jm1 = (j - R - 1 + 2 * WL) % WL, jmr = (j - 2 * R + 2 * WL) % WL; // rows t+1, t-1, t-r (row t+r is j)
 			const int pp = (int)((uint32_t)D1[jp1] - (uint32_t)D1[j]), pn = (int)((uint32_t)D1[jm1] - (uint32_t)D1[jmr]); // D1[] holds -D1 (see above)
 			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
-			const float dn = quot((float)min(min(pp, nn), min(pn, np))); // blobCenter(x, t), t = s0 + k
+			const int m_dn = min(min(pp, nn), min(pn, np)); // blobCenter(x, t) * r^2, t = s0 + k (satBlobCenter.cl:41)
 			const int t = s0 + k;
-			if(BCOUT && k >= 2 * R && t >= ya && t < yb && col_ok) bc_out[z * n + (size_t)t * w + x] = dn;
+			if(BCOUT && k >= 2 * R && t >= ya && t < yb && col_ok) bc_out[z * n + (size_t)t * w + x] = walk_quot<R>(m_dn);
 			const int y = t - 1; // the row whose four neighbours are now known
-			if(k >= 2 * R + 2 && y < yb) { // scalar condition
-				const float v = mid;
-				float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); // wave_shr:1: lane i <- lane i-1
-				float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); // wave_shl:1: lane i <- lane i+1
-				if(x_first) lf = v;
-				if(x_last) rt = v;
-				const float uv = y == 0 ? v : up, dv = y == h - 1 ? v : dn;
-				const bool above = col_ok && !(v < thr);                                   // blobList.cl:39
-				const bool peak = !(lf > v || rt > v || uv > v || dv > v);                 // :47-52, strict '>'
-				rej += __popcll(__ballot(above && !peak));                                 // :53 counter[2]++
-				// survivors (rare: ~130 per frame) are turned into records right here, one at a time by the whole wavefront -- the peak's
-				// value and its four neighbours are at hand, so nothing is recomputed and no candidate list exists (blobList.cl:57-102)
-				unsigned long long cm = __ballot(above && peak);
-				while(cm != 0) { // wave-uniform
-					const int b = __ffsll((long long)cm) - 1;
-					cm &= cm - 1;
-					const int px = __builtin_amdgcn_readlane(x, b);
-					const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
-					const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), b)), cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rt), b));
-					const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uv), b)), cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), b));
-					emit_record(fz, w, h, px, y, cv, cl, cr, cu, cd, min_score, list_radius, max_matches, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, lane);
-				}
-			}
-			up = mid;
-			mid = dn;
+			if(k >= 2 * R + 2 && y < yb) walk_detect<R>(m_up, m_mid, m_dn, col_ok, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			m_up = m_mid;
+			m_mid = m_dn;
 		}
 	}
 #undef VP_WK_ISSUE
@@ -481,7 +517,7 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 // A wavefront yields 62 - 2(r + o) columns.
 template<int RT, int OT>
 __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ flat, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work,
-		uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame, float thr, float min_score, int list_radius, int max_matches,
+		uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame, float thr, int m_thr, float min_score, int list_radius, int max_matches,
 		int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
@@ -506,23 +542,15 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	const bool g_ok = lane >= O && lane <= 63 - O && x >= 0 && x < w;      // gradientDot of this lane's column exists (its x +- o taps are in the wavefront)
 	const bool col_ok = lane >= R + O + 1 && lane <= 62 - R - O && x < w;   // this lane reports blobs (x >= 0 for these lanes)
 	const bool x_first = x == 0, x_last = x == w - 1;
-	const float div = (float)(R * R), rcp = 1.0f / div;
-	auto quot = [&](float m) {
-		if(R >= 3 && R <= 10) { // see k_circle_walk
-			const float q0 = m * rcp;
-			return __builtin_fmaf(__builtin_fmaf(-div, q0, m), rcp, q0);
-		}
-		return m / div;
-	};
 	int D1[WL], D2[WL]; // -D1 and D2 of the last WL table rows (k_circle_walk)
 	uint32_t FW[WFL], Pe[PF]; // own-column flat values of the last WFL rows; flat values of the next PF rows in flight
 #pragma unroll
 	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
 #pragma unroll
 	for(int j = 0; j < WFL; j++) FW[j] = 0;
-	float up = 0.f, mid = 0.f;
+	int m_up = 0, m_mid = 0; // integer quadrant minimum (blobCenter * r^2) of rows t-2, t-1 while row t is being formed
 	int rej = 0, S = 0; // S: this lane's column of the strip-local table
-	const uint32_t* fz = flat + z * n;
+	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
 	// step k loads flat row f = f0 + k, forms gradientDot / the table row t' = f - o (from k = 2o on: table origin row ya-1-r), blobCenter row
 	// t = t' - r (from k = 2o + 2r on: row ya - 1) and tests row y = t - 1
 	const int f0 = ya - 1 - R - O;
@@ -561,31 +589,11 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 			const int jp1 = (j - R + 1 + 2 * WL) % WL, jm1 = (j - R - 1 + 2 * WL) % WL, jmr = (j - 2 * R + 2 * WL) % WL; // table rows t+1, t-1, t-r (row t+r is j)
 			const int pp = (int)((uint32_t)D1[jp1] - (uint32_t)D1[j]), pn = (int)((uint32_t)D1[jm1] - (uint32_t)D1[jmr]);
 			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
-			const float dn = quot((float)min(min(pp, nn), min(pn, np))); // blobCenter(x, t), t = t' - r
+			const int m_dn = min(min(pp, nn), min(pn, np)); // blobCenter(x, t) * r^2, t = t' - r (satBlobCenter.cl:41)
 			const int y = tq - R - 1; // the row whose four neighbours are now known
-			if(k >= 2 * O + 2 * R + 2 && y < yb) { // scalar condition
-				const float v = mid;
-				float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); // lane i <- lane i-1
-				float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); // lane i <- lane i+1
-				if(x_first) lf = v;
-				if(x_last) rt = v;
-				const float uv = y == 0 ? v : up, dv = y == h - 1 ? v : dn;
-				const bool above = col_ok && !(v < thr);                   // blobList.cl:39
-				const bool peak = !(lf > v || rt > v || uv > v || dv > v); // :47-52
-				rej += __popcll(__ballot(above && !peak));                 // :53
-				unsigned long long cm = __ballot(above && peak);
-				while(cm != 0) { // wave-uniform: one record per survivor (blobList.cl:57-102)
-					const int b = __ffsll((long long)cm) - 1;
-					cm &= cm - 1;
-					const int px = __builtin_amdgcn_readlane(x, b);
-					const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
-					const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), b)), cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rt), b));
-					const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uv), b)), cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), b));
-					emit_record(fz, w, h, px, y, cv, cl, cr, cu, cd, min_score, list_radius, max_matches, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, lane);
-				}
-			}
-			up = mid;
-			mid = dn;
+			if(k >= 2 * O + 2 * R + 2 && y < yb) walk_detect<R>(m_up, m_mid, m_dn, col_ok, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			m_up = m_mid;
+			m_mid = m_dn;
 		}
 	}
 #undef VP_FW_ISSUE
@@ -626,10 +634,11 @@ int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w
 	const unsigned grid = (unsigned)(wpf * batch);
 	const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flat);
 	uint8_t* msorted = reinterpret_cast<uint8_t*>(matches);
+	const int m_thr = walk_threshold(thr, circle_radius);
 	bool launched = false;
 #define VP_FW(R, OO) \
 	if(!launched && circle_radius == R && grad_offset == OO) { \
-		k_flat_walk<R, OO><<<grid, 256, 0, s>>>(f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, min_score, radius, max_matches, order, msorted, idx); \
+		k_flat_walk<R, OO><<<grid, 256, 0, s>>>(f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx); \
 		launched = true; \
 	}
 	VP_FW(2, 1) VP_FW(3, 1) VP_FW(4, 1) VP_FW(5, 2) VP_FW(6, 2) VP_FW(7, 2) VP_FW(7, 3) VP_FW(8, 3) VP_FW(9, 3) VP_FW(9, 4) VP_FW(10, 4) VP_FW(11, 4) VP_FW(12, 4)
@@ -741,10 +750,11 @@ int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, con
 		const unsigned grid = (unsigned)(wpf * batch);
 		const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flat);
 		uint8_t* msorted = reinterpret_cast<uint8_t*>(matches);
+		const int m_thr = walk_threshold(thr, circle_radius);
 #define VP_WK(R) \
 		case R: \
-			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, min_score, radius, max_matches, order, msorted, idx); \
-			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, min_score, radius, max_matches, order, msorted, idx); \
+			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx); \
+			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx); \
 			break
 		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale))
 			VP_WK(2); VP_WK(3); VP_WK(4); VP_WK(5); VP_WK(6); VP_WK(7); VP_WK(8); VP_WK(9); VP_WK(10); VP_WK(11); VP_WK(12);
