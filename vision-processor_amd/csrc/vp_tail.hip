@@ -503,26 +503,48 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 
 
 // ---------------------------------------------------------------- VP_SAT_LOCAL: gradientDot + circle + blobList from flat -------------
-// The reference keeps its SAT private to rgba2blobCenter (Resources.cpp:155-163): nothing outside reads it.  Box sums with r <= 12 only need
-// a table that is consistent inside the box, so the walker above can carry its OWN strip-local table instead of reading the global one:
-//   a lane owns column x and walks down; per row it loads flat(x, y+o) (one dword), forms gradientDot(x, y) from the flat values of the lanes
-//   x +- o (ds_bpermute) and of its own column o rows up / down (register window), prefix-sums gradientDot across the wavefront (6 DPP adds:
-//   the row of a SAT whose origin is the strip's first column) and adds it to its running column sum: S(x, y), exact in wrapping int32.
-// Everything downstream is the walker: row differences D1 / D2 from the lanes x +- 1, x +- r, the four quadrant sums, blobCenter, the peak
-// test, record emission, the sort by the frame's last workgroup.  HBM traffic per frame: flat once (+ strip overlap) instead of flat + the
-// SAT written and read back: 53.5 MB -> ~31 MB at 2048x1536, and two launches become one.  Bit-identical to the global-table path: a box sum
-// is a difference of four table entries, and any origin gives the same difference (mod 2^32).
-// Clamp-to-edge: image columns < 0 have no gradientDot (their lanes add 0) and every tap address is clamped to the lane of column 0 / w-1;
-// rows > h-1 add nothing, so the table keeps its last row (= the clamped read); rows < 0 take D(0) (the windows are filled when row 0 is formed).
-// A wavefront yields 62 - 2(r + o) columns.
+// The reference keeps its SAT private to rgba2blobCenter (Resources.cpp:155-163): nothing outside reads it, and what `circle` takes from it are
+// four box sums of gradientDot.  With S the table and every tap clamped to the image (satBlobCenter.cl:20,37-40) the four quadrant terms are
+//     pp =  B(x+2, y+r)     np = -B(x-r+1, y+r)     nn =  B(x-r+1, y-1)     pn = -B(x+2, y-1)
+// where B(cx, ry) is the sum of gradientDot over the (r-1) x (r-1) box of columns cx .. cx+r-2 and rows ry-r+2 .. ry, taken on gradientDot
+// with its FIRST ROW AND FIRST COLUMN SET TO ZERO and zero outside the image.  (Why: S(x+r) - S(x+1) is the sum of the table's columns
+// x+2 .. x+r; a clamped upper tap ends the box at the image edge, which is zero extension; a clamped lower tap -- column x-r < 0 read as
+// column 0 -- subtracts column 0 as well, and column 0 lies in the box exactly in those cases; rows likewise.)  So no table is needed at all:
+// a lane owns a column and walks down the rows; per row it loads one flat pixel, forms gradientDot from the flat values of the lanes +- o
+// (ds_bpermute) and of its own column o rows up / down (register window), keeps the sum of the last r-1 rows of its column (add the new
+// value, subtract the one from r-1 rows ago) and sums that over r-1 neighbouring lanes by doubling (one DPP add, then ds_bpermute + add per
+// level): one row of B.  The lane keeps B of its own column start (for pp / pn) and, shifted by r+1 lanes, of the box left of it (nn / np)
+// for the last r+2 rows, takes the integer minimum, and from there on it is the walker above: integer threshold test, peak test, record
+// emission, sort by the frame's last workgroup.  ~18 VALU instructions and 4 cross-lane operations per pixel.
+// HBM traffic per frame: flat once (+ strip overlap) instead of flat + the SAT written and read back: 53.5 MB -> ~31 MB at 2048x1536, and
+// two launches become one.  Bit-identical to the table paths (exact wrapping int32 sums of the same values).
+// Lane l owns detection column x0 + l and the DATA column two to the right (the box of pp starts at x+2): no shift is needed for pp / pn.
+// A wavefront yields 63 - 2(r + o) columns.
+template<int N>
+__device__ __forceinline__ int lane_window_sum(int v, int lane) { // sum of v over lanes l .. l+N-1 (garbage in the last N-1 lanes)
+	int t2 = 0, t4 = 0, t8 = 0;
+	if(N >= 2) t2 = v + __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);                      // + lane l+1 (wave_shl:1)
+	if(N >= 4) t4 = t2 + __builtin_amdgcn_ds_bpermute(4 * ((lane + 2) & 63), t2);
+	if(N >= 8) t8 = t4 + __builtin_amdgcn_ds_bpermute(4 * ((lane + 4) & 63), t4);
+	int acc = 0, off = 0;
+	if(N & 8) { acc = t8; off = 8; }
+	if(N & 4) { acc = off ? acc + __builtin_amdgcn_ds_bpermute(4 * ((lane + off) & 63), t4) : t4; off += 4; }
+	if(N & 2) { acc = off ? acc + __builtin_amdgcn_ds_bpermute(4 * ((lane + off) & 63), t2) : t2; off += 2; }
+	if(N & 1) { acc = off ? acc + __builtin_amdgcn_ds_bpermute(4 * ((lane + off) & 63), v) : v; off += 1; }
+	return acc;
+}
+
 template<int RT, int OT>
 __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ flat, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work,
 		uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame, float thr, int m_thr, float min_score, int list_radius, int max_matches,
 		int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
-	constexpr int R = RT, O = OT, PF = 4, WFL = ((2 * O + 1 + 3) / 4) * 4, WL = ((2 * R + 1 + WFL - 1) / WFL) * WFL, USE = 62 - 2 * (R + O);
-	static_assert(USE >= 16 && WL % WFL == 0 && WFL % PF == 0, "window geometry");
+	constexpr int R = RT, O = OT, PF = 4, NB = R - 1;                        // NB: box side
+	constexpr int WFL = ((2 * O + 1 + 3) / 4) * 4;                            // own-column flat window (rows t'-o .. t'+o), a multiple of PF
+	constexpr int RING = ((R + 2 + WFL - 1) / WFL) * WFL;                     // ring length of the row windows: >= r+2, a multiple of WFL; the loop is unrolled RING-fold
+	constexpr int LO = R + O + 2, HI = 64 - R - O, USE = HI - LO + 1;         // lanes that report blobs: their boxes, gradientDot taps and peak-test neighbours are in the wavefront
+	static_assert(USE >= 16 && RING % WFL == 0 && WFL % PF == 0 && NB >= 1 && NB <= 11, "window geometry");
 	const int lane = threadIdx.x & 63;
 	const unsigned lb = vp_xcd_remap(blockIdx.x, gridDim.x);
 	const int z = (int)(lb / (unsigned)wgs_per_frame);
@@ -531,67 +553,53 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	if(item < items_per_frame) { // wave-uniform: the padding wavefronts only take part in the arrival below
 	const int strip = item % strips_x, seg = item / strips_x;
 	const int ya = seg * seg_h, yb = min(h, ya + seg_h);
-	const int x0 = strip * USE - (R + O + 1), x = x0 + lane; // column of lane 0, of this lane
-	const uint32_t oe = 4u * (uint32_t)vp_clampi(x, 0, w - 1);
-	// tap lanes, clamp-to-edge on the column (gradientDot.cl:20, satBlobCenter.cl:20): lane of column clamp(x + d)
-	auto tap = [&](int d) { return 4 * ((vp_clampi(x + d, 0, w - 1) - x0) & 63); };
-	int a_fp = tap(O), a_fn = tap(-O), a_hi = tap(R), a_p1 = tap(1), a_m1 = tap(-1), a_lo = tap(-R);
-	asm volatile("" : "+v"(a_fp), "+v"(a_fn), "+v"(a_hi), "+v"(a_p1), "+v"(a_m1), "+v"(a_lo));
+	const int x = strip * USE - LO + lane, xd = x + 2; // detection column, data column
+	const uint32_t oe = 4u * (uint32_t)vp_clampi(xd, 0, w - 1); // clamp-to-edge on the column (gradientDot.cl:20): the lanes +- o then hold flat(clamp(xd +- o))
+	int a_fp = 4 * ((lane + O) & 63), a_fn = 4 * ((lane - O) & 63), a_bn = 4 * ((lane - (R + 1)) & 63);
+	asm volatile("" : "+v"(a_fp), "+v"(a_fn), "+v"(a_bn));
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(flat + z * n), 0, (int)(n * 4), 0x00020000); // host: n * 4 < 2^31
 	const uint32_t row_bytes = (uint32_t)w * 4u;
-	const bool g_ok = lane >= O && lane <= 63 - O && x >= 0 && x < w;      // gradientDot of this lane's column exists (its x +- o taps are in the wavefront)
-	const bool col_ok = lane >= R + O + 1 && lane <= 62 - R - O && x < w;   // this lane reports blobs (x >= 0 for these lanes)
+	const bool g_ok = lane >= O && lane <= 63 - O && xd >= 1 && xd < w;   // gradientDot of the data column counts: inside the image, not column 0, taps in the wavefront
+	const bool col_ok = lane >= LO && lane <= HI && x < w;                 // this lane reports blobs (x >= 0 for these lanes)
 	const bool x_first = x == 0, x_last = x == w - 1;
-	int D1[WL], D2[WL]; // -D1 and D2 of the last WL table rows (k_circle_walk)
 	uint32_t FW[WFL], Pe[PF]; // own-column flat values of the last WFL rows; flat values of the next PF rows in flight
-#pragma unroll
-	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
+	int GW[RING], BP[RING], BN[RING]; // gradientDot of the data column, B(x+2, .), B(x-r+1, .) of the last RING rows
 #pragma unroll
 	for(int j = 0; j < WFL; j++) FW[j] = 0;
-	int m_up = 0, m_mid = 0; // integer quadrant minimum (blobCenter * r^2) of rows t-2, t-1 while row t is being formed
-	int rej = 0, S = 0; // S: this lane's column of the strip-local table
+#pragma unroll
+	for(int j = 0; j < RING; j++) GW[j] = BP[j] = BN[j] = 0;
+	int V = 0, rej = 0, m_up = 0, m_mid = 0; // V: sum of the last r-1 gradientDot rows of the data column; m_*: integer quadrant minimum of rows y-2, y-1
 	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
-	// step k loads flat row f = f0 + k, forms gradientDot / the table row t' = f - o (from k = 2o on: table origin row ya-1-r), blobCenter row
-	// t = t' - r (from k = 2o + 2r on: row ya - 1) and tests row y = t - 1
-	const int f0 = ya - 1 - R - O;
-	const int nsteps = 2 * O + 2 * R + (yb - ya) + 2;
+	// step k loads flat row f = f0 + k, forms gradientDot row t' = f - o (from k = 2o on: row ya - r, the first row of the first box needed) and
+	// the box row B(., t'), the quadrant minimum of row y = t' - r (boxes ending at rows y + r and y - 1) and tests row y - 1
+	const int f0 = ya - R - O;
+	const int nsteps = 2 * R + 2 * O + 1 + (yb - ya);
 #define VP_FW_ISSUE(SLOT, K) Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)vp_clampi(f0 + (K), 0, h - 1) * row_bytes, 0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_FW_ISSUE(p, p);
-	for(int kb = 0; kb < nsteps; kb += WL) {
+	for(int kb = 0; kb < nsteps; kb += RING) {
 #pragma unroll
-		for(int j = 0; j < WL; j++) {
+		for(int j = 0; j < RING; j++) {
 			const int k = kb + j;
 			const uint32_t e = Pe[j % PF];
 			VP_FW_ISSUE(j % PF, k + PF);
 			FW[j % WFL] = e;
-			const int tq = f0 + k - O; // table row t'
+			const int tq = f0 + k - O; // gradientDot / box row t'
 			{
-				const uint32_t c = FW[(j - O + 2 * WFL) % WFL], yn = FW[(j - 2 * O + 2 * WFL) % WFL]; // flat(x, t'), flat(x, t' - o); e = flat(x, t' + o)
+				const uint32_t c = FW[(j - O + 2 * WFL) % WFL], yn = FW[(j - 2 * O + 2 * WFL) % WFL]; // flat(xd, t'), flat(xd, t' - o); e = flat(xd, t' + o)
 				const uint32_t xp = (uint32_t)__builtin_amdgcn_ds_bpermute(a_fp, (int)c), xn = (uint32_t)__builtin_amdgcn_ds_bpermute(a_fn, (int)c);
 				int g = grad_dot_pk(xp, xn, e, yn); // gradientDot.cl:25-29
-				if(!(g_ok && k >= 2 * O && tq >= 0 && tq < h)) g = 0;
-				S += scan_incl_dpp(g);
+				if(!(g_ok && k >= 2 * O && tq >= 1 && tq < h)) g = 0; // outside the image, row 0 and column 0 contribute nothing (see above)
+				V += g - GW[(j - NB + 2 * RING) % RING]; // the value from r-1 rows ago leaves the window
+				GW[j] = g;
 			}
-			{
-				const int sa = __builtin_amdgcn_ds_bpermute(a_hi, S), sd = __builtin_amdgcn_ds_bpermute(a_lo, S);
-				const int sb = __builtin_amdgcn_ds_bpermute(a_p1, S), sc = __builtin_amdgcn_ds_bpermute(a_m1, S);
-				D1[j] = (int)((uint32_t)sb - (uint32_t)sa);
-				D2[j] = (int)((uint32_t)sc - (uint32_t)sd);
-			}
-			if(tq == 0) { // rows above the image read row 0 (clamp-to-edge): every window slot of a negative row takes D(0)
-#pragma unroll
-				for(int q = 0; q < WL; q++) {
-					D1[q] = D1[j];
-					D2[q] = D2[j];
-				}
-			}
-			const int jp1 = (j - R + 1 + 2 * WL) % WL, jm1 = (j - R - 1 + 2 * WL) % WL, jmr = (j - 2 * R + 2 * WL) % WL; // table rows t+1, t-1, t-r (row t+r is j)
-			const int pp = (int)((uint32_t)D1[jp1] - (uint32_t)D1[j]), pn = (int)((uint32_t)D1[jm1] - (uint32_t)D1[jmr]);
-			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
-			const int m_dn = min(min(pp, nn), min(pn, np)); // blobCenter(x, t) * r^2, t = t' - r (satBlobCenter.cl:41)
+			const int bp = lane_window_sum<NB>(V, lane);      // B(x+2, t')
+			BP[j] = bp;
+			BN[j] = __builtin_amdgcn_ds_bpermute(a_bn, bp);   // B(x-r+1, t'): the box r+1 columns to the left
+			const int jo = (j - (R + 1) + 2 * RING) % RING;   // row t' - r - 1 = y - 1
+			const int m_dn = min(min(BP[j], BN[jo]), -max(BP[jo], BN[j])); // min(pp, nn, pn, np) of row y = t' - r (satBlobCenter.cl:37-41, times r^2)
 			const int y = tq - R - 1; // the row whose four neighbours are now known
-			if(k >= 2 * O + 2 * R + 2 && y < yb) walk_detect<R>(m_up, m_mid, m_dn, col_ok, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			if(k >= 2 * R + 2 * O + 1 && y < yb) walk_detect<R>(m_up, m_mid, m_dn, col_ok, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
 			m_up = m_mid;
 			m_mid = m_dn;
 		}
@@ -616,7 +624,7 @@ int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w
 	const bool raster = order == VP_ORDER_RASTER;
 	uint32_t* idx_work = (raster || !idx) ? ws.idx : idx;
 	uint8_t* rec_work = raster ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
-	const int use = 62 - 2 * (circle_radius + grad_offset);
+	const int use = 63 - 2 * (circle_radius + grad_offset);
 	VP_REQUIRE(use >= 16, "VP_SAT_LOCAL: circle radius %d + gradient offset %d too large for a wavefront strip", circle_radius, grad_offset);
 	const int strips_x = (int)vp_div_up(w, use);
 	int seg_h = ctx->tune.tail_segment_rows;
