@@ -277,7 +277,11 @@ def test_native_multi_gpu_feeds_gather_through_rccl(port):
     out = subprocess.run([exe, "--gpus", str(n), str(feeds), "3", "1", "--verify"], capture_output=True, text=True, timeout=600, env=envv)
     assert out.returncode == 0, out.stdout + out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["gpus"] == n and r["gather_verified"] is True and "ncclAllGather" in r["gather"]
+    assert r["gpus"] == n and r["gather_verified"] is True and "ncclAllGather" in r["gather"] and r["sat_variant"] == "tiled"
+    out2 = subprocess.run([exe, "--gpus", str(n), str(feeds), "3", "1", "--verify", "--local"], capture_output=True, text=True, timeout=600, env=envv)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    r2 = json.loads(out2.stdout.strip().splitlines()[-1])
+    assert r2["gather_verified"] is True and r2["sat_variant"] == "local" and r2["counters"] == r["counters"]  # the variant without a global table: same lists
     cfg = cfgs.CFG2
     big = O.Port(threads=8)
     for g in range(min(n, 2)):

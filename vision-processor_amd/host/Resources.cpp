@@ -1,3 +1,7 @@
+// CALLER SIDE of the drop-in, not product logic.  raw2quad(), quad2rgba(), rgba2blobCenter(), streamQuad() and streamImage() below are the
+// reference's own call sequences (src/Resources.cpp:138-186) written down again, statement for statement, against the facade of host/opencl.h:
+// their point is to show -- and, through tests/test_gpu_facade.py, to check on the GPU -- that the reference's call sites compile and run
+// unchanged on the new runtime.  Nothing here computes anything; the work happens behind OpenCL::run / await in libvp_hip.so.
 #include "Resources.h"
 
 #include <vector>

@@ -4,7 +4,8 @@
 // This is the loop of src/main.cpp:262-372 for many cameras at once: what a deployment that puts several cameras on one MI355X runs.
 //
 // usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1]
-//        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--verify]     (feeds_multi.cpp: N devices, RCCL gather of the records)
+//        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--verify] [--local]   (feeds_multi.cpp: N devices, RCCL gather of the records;
+//                                                                                             --local = VP_SAT_LOCAL, no global table)
 // Scene and geometry: SURVEY.md 8(d) cfg2 (2048x1536 RGGB, nadir camera 5 m over a 9.6 x 7.2 m patch, 16 robots, 8 balls per feed).
 #include <chrono>
 #include <cmath>
@@ -25,7 +26,7 @@
 		} \
 	} while(0)
 
-int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify); // feeds_multi.cpp
+int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify, int local); // feeds_multi.cpp
 
 // cfg2: kernel scalars assigned directly
 void vp_feeds_cfg2_params(VpFrameParams* out) {
@@ -58,16 +59,17 @@ void vp_feeds_cfg2_params(VpFrameParams* out) {
 
 int main(int argc, char** argv) {
 	if(argc > 2 && strcmp(argv[1], "--gpus") == 0) {
-		int verify = 0, pos[3] = {128, 20, 3}, np = 0;
+		int verify = 0, local = 0, pos[3] = {128, 20, 3}, np = 0;
 		for(int i = 3; i < argc; i++) {
 			if(strcmp(argv[i], "--verify") == 0) verify = 1;
+			else if(strcmp(argv[i], "--local") == 0) local = 1;
 			else if(np < 3) pos[np++] = atoi(argv[i]);
 		}
 		if(pos[0] < 1 || pos[1] < 1 || pos[2] < 0) {
-			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--verify]\n");
+			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--verify] [--local]\n");
 			return 2;
 		}
-		return vp_feeds_run_multi(atoi(argv[2]), pos[0], pos[1], pos[2], verify);
+		return vp_feeds_run_multi(atoi(argv[2]), pos[0], pos[1], pos[2], verify, local);
 	}
 	const int feeds = argc > 1 ? atoi(argv[1]) : 128, steps = argc > 2 ? atoi(argv[2]) : 20, warmup = argc > 3 ? atoi(argv[3]) : 3;
 	const int threads = argc > 4 ? atoi(argv[4]) : 16, detect = argc > 5 ? atoi(argv[5]) : 1;

@@ -25,7 +25,7 @@
 
 void vp_feeds_cfg2_params(VpFrameParams* p); // feeds_main.cpp
 
-int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify) {
+int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify, int local) {
 	const int visible = vp_device_count();
 	if(gpus < 1 || gpus > visible) {
 		fprintf(stderr, "[FATAL] --gpus %d but %d HIP device(s) are visible\n", gpus, visible);
@@ -33,6 +33,7 @@ int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify) {
 	}
 	VpFrameParams p;
 	vp_feeds_cfg2_params(&p);
+	if(local) p.sat_variant = VP_SAT_LOCAL; // no global table: resampling + ONE kernel per step and device
 	const int qw = p.qw, qh = p.qh, mm = p.max_matches;
 	const size_t rawBytes = (size_t)4 * qw * qh, npx = (size_t)p.fw * p.fh;
 	size_t offC = 0, offM = 0, offI = 0;
@@ -59,7 +60,7 @@ int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify) {
 				VpFrameBuffers& b = buf[(size_t)g * 2 + s];
 				memset(&b, 0, sizeof(b));
 				CK(vp_malloc_device(ctx[g], npx * 4 * feeds, (void**)&b.flat));
-				CK(vp_malloc_device(ctx[g], npx * 4 * feeds, (void**)&b.sat));
+				if(!local) CK(vp_malloc_device(ctx[g], npx * 4 * feeds, (void**)&b.sat));
 				uint8_t* rec = static_cast<uint8_t*>(vp_gather_send(gather, g, s)); // vp_frame writes its outputs into the record block itself
 				b.counter = reinterpret_cast<int32_t*>(rec + offC);
 				b.matches = reinterpret_cast<VpMatch*>(rec + offM);
@@ -105,8 +106,8 @@ int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify) {
 		}
 	}
 	long blobs = 0;
-	printf("{\"program\": \"vp_feeds\", \"gpus\": %d, \"feeds_per_gpu\": %d, \"steps\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"record_bytes_per_gpu\": %zu, \"gather\": \"RCCL ncclAllGather, one grouped call per step, %d rank(s) in one process\"",
-			gpus, feeds, steps, (double)gpus * feeds * steps / dt, 1e3 * dt / steps, recBytes, gpus);
+	printf("{\"program\": \"vp_feeds\", \"gpus\": %d, \"feeds_per_gpu\": %d, \"steps\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"record_bytes_per_gpu\": %zu, \"gather\": \"RCCL ncclAllGather, one grouped call per step, %d rank(s) in one process\", \"sat_variant\": \"%s\"",
+			gpus, feeds, steps, (double)gpus * feeds * steps / dt, 1e3 * dt / steps, recBytes, gpus, local ? "local" : "tiled");
 	printf(", \"counters\": [");
 	for(int g = 0; g < gpus; g++) {
 		const int32_t* c = reinterpret_cast<const int32_t*>(own.data() + (size_t)g * recBytes + offC);
