@@ -89,7 +89,8 @@ const char* vp_device_name(VpContext* ctx);
 /* Result-neutral tuning (every value gives bit-identical output; the library reads no environment variable):
  *   "sat_workgroups_per_cu" 2..8 (0 = automatic, the default), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_float_stage" 0 / 1 (default 1),
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
- *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic).  Applies to launches issued after the call. */
+ *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
+ *   write the dense halo strips the tiled SAT pass reads).  Applies to launches issued after the call. */
 int vp_ctx_tune(VpContext* ctx, const char* key, int value);
 
 /* per-launch timing, the analogue of the stored cl::Event list (opencl.h:84, opencl.cpp:94-105).  When enabled every
@@ -178,13 +179,14 @@ int vp_sat(VpContext* ctx, int stream, const float* graddot, int w, int h, int b
 int vp_graddot_sat(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, int variant,
 		int32_t* sat, float* graddot_out);
 
-/* Halo strips: the first and the last `offset` flat pixels of every 64-pixel tile row, in two dense arrays per frame:
- * FIRST[tile column][row][offset] followed by LAST[tile column][row][offset].  The single-pass SAT needs an `offset` wide
- * horizontal halo on both sides of a tile; fetched from `flat` that halo costs one 128-byte line per row and side (measured:
- * 1.51x the algorithmic bytes of the pass), fetched from the neighbours' arrays it is dense (1.16x).  vp_frame lets the
- * resampling kernel emit both arrays while it writes flat (one masked store per 64-pixel row); vp_halo_strips builds them from
- * an existing flat.  Requires w % 64 == 0 and 1 <= offset <= 4 (vp_halo_strip_bytes returns 0 otherwise and the strips are
- * simply not used).  Size per frame: 2 * (w / 64) * h * offset * 4 bytes. */
+/* Halo strips: the first and the last `offset` flat pixels of every 64-pixel tile row, one record of 2 * offset pixels per tile column and
+ * row: strips[((tile column * hp + row) * 2 + side) * offset + k], side 0 = first / 1 = last pixels, hp = h rounded up to a multiple of 4.
+ * The single-pass SAT needs an `offset` wide horizontal halo on both sides of a tile; fetched from `flat` that halo costs one 128-byte line
+ * per row and side (measured: 1.51x the algorithmic bytes of the pass), fetched from the neighbours' records it is dense (1.16x).  vp_frame
+ * lets the resampling kernel emit the records while it writes flat (the four rows of a workgroup are one contiguous 64-byte store at
+ * offset 2); vp_halo_strips builds them from an existing flat.  The layout is private to the library: treat the buffer as opaque.
+ * Requires w % 64 == 0 and 1 <= offset <= 4 (vp_halo_strip_bytes returns 0 otherwise and the strips are simply not used).
+ * Size per frame: 2 * (w / 64) * hp * offset * 4 bytes. */
 size_t vp_halo_strip_bytes(int w, int h, int offset);
 int vp_halo_strips(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int offset, int batch, uint32_t* strips);
 int vp_graddot_sat_strips(VpContext* ctx, int stream, const uint8_t* flat, const uint32_t* strips, int w, int h, int offset, int batch, int variant,

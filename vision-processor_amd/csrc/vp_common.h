@@ -47,6 +47,7 @@ struct VpTuning {
 	int resample_float_stage = 1;  // staged Bayer resampling, BILINEAR_RTZ: box staged as floats (1) or bytes (0)
 	int resample_bgr_staged = 1;   // BGR8 sensors: staged kernel (1) or the generic mapped kernel (0)
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
+	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
 };
 
@@ -148,11 +149,11 @@ static inline unsigned vp_div_up(unsigned a, unsigned b) { return (a + b - 1) / 
 // contiguous over rows, so every fetched line is used whole.
 struct VpStrips {
 	uint32_t* base;       // nullptr: not in use
-	int tiles_x, h, o;
-	size_t frame_words;   // uint32 per frame = 2 * tiles_x * h * o
-	__host__ __device__ size_t rec(int j, int y, int e) const { // e < o: FIRST, else LAST
-		return e < o ? ((size_t)j * h + y) * o + e : ((size_t)(tiles_x + j) * h + y) * o + (e - o);
-	}
+	int tiles_x, h, hp, o; // hp = h rounded up to a multiple of 4 (rows of a resampling workgroup)
+	size_t frame_words;   // uint32 per frame = tiles_x * hp * 2 * o
+	// One record of 2 o pixels per tile j and row y: [FIRST o pixels | LAST o pixels] of that 64-pixel tile row.  The four rows a resampling
+	// workgroup produces are contiguous (8 o dwords: one aligned 64-byte store for o = 2).
+	__host__ __device__ size_t rec(int j, int y, int e) const { return ((size_t)j * hp + y) * 2 * o + e; } // e < o: FIRST, else LAST
 	__host__ __device__ size_t left(int b, int y, int k) const { return rec(b - 1, y, o + k); } // flat[y][64 b - o + k], b >= 1
 	__host__ __device__ size_t right(int b, int y, int k) const { return rec(b, y, k); }        // flat[y][64 b + k]
 };
@@ -162,8 +163,9 @@ static inline VpStrips vp_make_strips(uint32_t* base, int w, int h, int offset) 
 	s.base = base;
 	s.tiles_x = w / 64;
 	s.h = h;
+	s.hp = (h + 3) & ~3;
 	s.o = offset;
-	s.frame_words = (size_t)2 * s.tiles_x * h * offset;
+	s.frame_words = (size_t)2 * s.tiles_x * s.hp * offset;
 	return s;
 }
 

@@ -27,7 +27,7 @@ extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, cons
 	// halo strips for the single-pass SAT: written by whichever resampling kernel produces flat (6 % of flat, saves the SAT
 	// kernel a 128-byte line per row and side of every tile)
 	VpStrips strips = vp_make_strips(nullptr, 64, 1, 1);
-	const size_t strip_bytes = p->sat_variant == VP_SAT_TILED ? vp_halo_strip_bytes(p->fw, p->fh, p->grad_offset) : 0;
+	const size_t strip_bytes = p->sat_variant == VP_SAT_TILED && ctx->tune.sat_halo_strips ? vp_halo_strip_bytes(p->fw, p->fh, p->grad_offset) : 0;
 	if(strip_bytes) {
 		void* sp = nullptr;
 		VP_TRY(vp_workspace(ctx, stream, 3, strip_bytes * (size_t)batch, &sp));

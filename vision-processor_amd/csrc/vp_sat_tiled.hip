@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 		const int tjx = X0 >> 6;
 		const bool border = right ? tjx + 1 >= a.tilesX : tjx == 0;
 		if(use_strips && !border) { // right halo: FIRST pixels of tile tjx + 1; left halo: LAST pixels of tile tjx - 1 (VpStrips::rec)
-			const int j = right ? tjx + 1 : a.tilesX + tjx - 1;
-			return __builtin_amdgcn_raw_buffer_load_b32(rs_strip, (gy * (uint32_t)O + (uint32_t)k) * 4u, (uint32_t)j * (uint32_t)h * (uint32_t)O * 4u, 0);
+			const int j = right ? tjx + 1 : tjx - 1;
+			return __builtin_amdgcn_raw_buffer_load_b32(rs_strip, (gy * 2u * (uint32_t)O + (right ? 0u : (uint32_t)O) + (uint32_t)k) * 4u, (uint32_t)j * (uint32_t)a.strips.hp * 2u * (uint32_t)O * 4u, 0);
 		}
 		if(border) return __builtin_amdgcn_raw_buffer_load_b32(rs_flat, gy * row_bytes, right ? row_bytes - 4u : 0u, 0); // edge column replicated
 		// (the column clamp only acts next to a partial last tile column: its first pixels may already lie past the image)
