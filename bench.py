@@ -497,7 +497,7 @@ def main():
     if rank == 0:
         cnt = cnt_now
         if args.sat == "local":  # no SAT pass exists: the fused kernel reads flat once (4 B/px algorithmic)
-            roof_kernel, sat_ms, algo_bytes = "gradientDot+circle+blobList, strip-local table (reads flat once)", float(np.mean(stage_ms["gradientDot+satBlobCenter+blobList (local)"])), 4.0 * cfg.n_flat * B
+            roof_kernel, sat_ms, algo_bytes = "gradientDot+circle+blobList from sliding box sums, no table (reads flat once)", float(np.mean(stage_ms["gradientDot+satBlobCenter+blobList (local)"])), 4.0 * cfg.n_flat * B
         else:
             roof_kernel, sat_ms, algo_bytes = "gradientDot+SAT pass", float(np.mean(stage_ms["gradientDot+sat"])), 8.0 * cfg.n_flat * B
         achieved = algo_bytes / (sat_ms * 1e-3) / 1e9
@@ -522,6 +522,11 @@ def main():
             "stage_ms_per_step": {k: round(float(np.mean(v)), 4) for k, v in stage_ms.items()},
             "blobs_per_frame": float(np.minimum(cnt[:, 0], mm).mean()),
         }
+        # every stage against the same HBM roofline, on its own algorithmic bytes per flat pixel: raw sensor byte + flat
+        # written (resampling), flat read + table written (SAT pass), table read (circle + blobList), flat read (local variant)
+        per_px = {"raw2quad+resampling": 4.0 + cfg.qw * cfg.qh * (3.0 if cfg.layout == vp.configs.BGR else 4.0) / cfg.n_flat, "gradientDot+sat": 8.0, "satBlobCenter+blobList": 4.0,
+                  "gradientDot+satBlobCenter+blobList (local)": 4.0}
+        out["stage_roofline_frac"] = {k: round(per_px[k] * cfg.n_flat * B / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in stage_ms.items() if k in per_px}
         if det is not None:
             # what the last step emitted: parse this rank's packets back (and, for N > 1, check that the gather delivered every rank's)
             torch.cuda.synchronize()
