@@ -24,6 +24,8 @@ rep("		lds_barrier();\n\n		// ---- C/D: aggregates, publication, look-back", "		
 rep("		lds_barrier();\n		const int K = misc[1];", "		lds_barrier();\n		TR(4);\n		const int K = misc[1];")
 rep("		if(!more) break;\n		rem = next;\n		lds_barrier(); // T16 / Rc / Av / Bv / misc of this tile are dead only now (phase E read them)",
     "		TR(5);\n		trn++;\n		if(!more) break;\n		rem = next;\n		lds_barrier(); // T16 / Rc / Av / Bv / misc of this tile are dead only now (phase E read them)")
+rep("		// ---- E: out = local + (sub-segment totals above) + A(x) + B(y) + K, for the lane's own 16 pixels --------------------\n",
+    "		TR(6);\n		// ---- E: out = local + (sub-segment totals above) + A(x) + B(y) + K, for the lane's own 16 pixels --------------------\n")
 rep("int vp_check_timeout(VpContext* ctx, int stream);",
     "int vp_check_timeout(VpContext* ctx, int stream);\nstatic unsigned long long* g_trace = nullptr;\n"
     "extern \"C\" int vp_dbg_trace_copy(void* host, size_t bytes) { return g_trace ? (int)hipMemcpy(host, g_trace, bytes, hipMemcpyDeviceToHost) : -1; }\n"

@@ -27,7 +27,7 @@ us = lambda x: (x - t0) / 100.0   # s_memrealtime: 100 MHz
 wg = np.where(used[:, 0])[0]
 print(f"B={B}: {len(wg)} workgroups, {used.sum()} tiles traced; kernel span {us(t[:, :, 5][used].max()):.1f} us")
 start = us(t[wg, 0, 0]); print(f"workgroup start: min {start.min():.1f} p50 {np.median(start):.1f} p90 {np.percentile(start, 90):.1f} max {start.max():.1f} us")
-for name, a, b in (("A  (commit prefetch -> LDS)", 1, 2), ("B  (local SAT)", 2, 3), ("CD (publish + look-back)", 3, 4), ("E  (+prefetch issue, stores)", 4, 5)):
+for name, a, b in (("A  (commit prefetch -> LDS)", 1, 2), ("B  (local SAT)", 2, 3), ("CD (publish + look-back)", 3, 4), ("E0 (K publish + prefetch issue)", 4, 6), ("E1 (adds + stores)", 6, 5)):
     d = (t[:, :, b] - t[:, :, a])[used] / 100.0
     print(f"  {name:30s} mean {d.mean():6.2f}  p50 {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
 first = (t[:, 0, 1] - t[:, 0, 0])[used[:, 0]] / 100.0
