@@ -424,3 +424,45 @@ def test_local_table_variant_equals_the_global_table_path(env, cfg):
             assert np.array_equal(a[2][i, :nrec], b[2][i, :nrec]) and a[1][i, :nrec * 22].tobytes() == b[1][i, :nrec * 22].tobytes(), i
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [cfgs.T_MID, cfgs.T_RAGGED.with_(name="t_ragged_even", qw=68, qh=46), cfgs.CFG2], ids=lambda c: c.name)
+def test_tuning_knobs_are_result_neutral(env, cfg):
+    """vp_ctx_tune promises bit-identical output for every value: halo strip records on / off, 2..6 resident SAT workgroups per CU, both
+    resampling stage formats and tile mappings, three rows-per-wavefront settings of the tail -- flat, SAT, counters, records all equal."""
+    capi, torch = env
+    B, mm = 5, cfg.max_matches
+    raws = dev(torch, np.stack([cfg.synth(5100 + i) for i in range(B)]))
+    p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
+    want = None
+    for knobs in ({}, {"sat_halo_strips": 0}, {"sat_workgroups_per_cu": 2}, {"sat_workgroups_per_cu": 6}, {"resample_float_stage": 0}, {"resample_xcd_bands": 1},
+                  {"resample_xcd_bands": 0, "tail_segment_rows": 16}, {"tail_segment_rows": 192, "sat_halo_strips": 0}, {"candidate_capacity": 8}):
+        ctx = capi.Context(0, n_streams=1)
+        try:
+            for k, v in knobs.items():
+                ctx.tune(k, v)
+            flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+            sat = torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
+            m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda")
+            idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+            cnt = torch.full((B, 3), -9, dtype=torch.int32, device="cuda")
+            for rep in range(2):
+                ctx.frame(p, raws, B, flat, sat, m, cnt, idx=idx)
+            ctx.sync()
+            got = (flat.cpu().numpy(), sat.cpu().numpy(), cnt.cpu().numpy(), idx.cpu().numpy(), m.cpu().numpy())
+        finally:
+            ctx.close()
+        if want is None:
+            want = got
+            assert int(got[2][:, 0].min()) > 0
+            continue
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), knobs
+        for i in range(B):
+            nrec = min(int(want[2][i, 0]), mm)
+            assert np.array_equal(got[3][i, :nrec], want[3][i, :nrec]) and got[4][i, :nrec * 22].tobytes() == want[4][i, :nrec * 22].tobytes(), (knobs, i)
+    with pytest.raises(Exception):
+        ctx = capi.Context(0, n_streams=1)
+        try:
+            ctx.tune("no_such_knob", 1)
+        finally:
+            ctx.close()
