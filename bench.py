@@ -173,7 +173,7 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
                 continue
             sweep[str(b)] = round(rate(lambda: ctx.frame(params, d_raw, b, flat, sat, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
         out["frames_per_s_by_frames_per_launch"] = sweep
-        # The optional variant without a global table (sat_variant = VP_SAT_LOCAL: gradientDot + strip-local table + circle + blobList in one
+        # The optional variant without a global table (sat_variant = VP_SAT_LOCAL: gradientDot + sliding box sums + circle + blobList in one
         # kernel, flat read once, buffers.sat = NULL).  Same blob list bit for bit (tests/test_gpu_round2.py); the headline keeps the SAT pass.
         p_local = capi.frame_params(cfg, sat_variant=capi.SAT_LOCAL, order=params.order)
         local = {}

@@ -45,7 +45,7 @@ typedef enum { VP_SAMPLER_NEAREST = 0, VP_SAMPLER_BILINEAR_RTZ = 1 } VpSamplerMo
  * exact, and equal the reference's binary32 SAT whenever max|SAT| < 2^24.
  *   TILED    : single pass, LDS-tiled local scans + decoupled look-back of tile carries (8 B/px HBM traffic)
  *   TWOPASS  : global row pass then column pass ("global-recursive" comparison variant, 16 B/px)
- *   LOCAL    : vp_frame / vp_flat_bloblist only -- no global table at all: gradientDot, a strip-local table, circle and blobList in ONE kernel that
+ *   LOCAL    : vp_frame / vp_flat_bloblist only -- no table at all: gradientDot, sliding box sums of it (what circle takes from the SAT), circle and blobList in ONE kernel that
  *              reads flat once (the reference keeps its SAT private to rgba2blobCenter, Resources.cpp:155-163).  VpFrameBuffers.sat, .graddot
  *              and .blobcenter must be NULL.  Same blob list, bit for bit; TILED stays the default and the pass the roofline is quoted on. */
 typedef enum { VP_SAT_TILED = 0, VP_SAT_TWOPASS = 1, VP_SAT_LOCAL = 2 } VpSatVariant;
