@@ -16,14 +16,15 @@ mm = cfg.max_matches
 d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
          matches=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"),
          counter=torch.zeros((B, 3), dtype=torch.int32, device="cuda"))
-p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+ORDER = capi.ORDER_ATOMIC if os.environ.get("VP_TB_ORDER") == "atomic" else capi.ORDER_RASTER  # VP_TB_ORDER=atomic: no sort by the last workgroup
+p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=ORDER)
 ctx.frame(p, raw, B, **d); ctx.sync()
 res = {v: [] for v in variants}
 def run(N=10):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(N):
-        ctx.blobcenter_list(d["flat"], d["sat"], cfg.fw, cfg.fh, B, cfg.circle_radius, cfg.circ_threshold, cfg.min_score, cfg.list_radius, mm, capi.ORDER_RASTER,
+        ctx.blobcenter_list(d["flat"], d["sat"], cfg.fw, cfg.fh, B, cfg.circle_radius, cfg.circ_threshold, cfg.min_score, cfg.list_radius, mm, ORDER,
                             d["matches"], d["idx"], d["counter"])
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / N * 1000

@@ -185,7 +185,7 @@ __device__ __forceinline__ float disc_score_wave(const uint32_t* __restrict__ f,
 
 // Last-workgroup-done (cdna_hip_programming.md Guideline 16, R1): the records of a frame were stored write-through by whichever
 // workgroups found them; every storing wave drains its stores, the workgroup meets at a barrier, then ONE lane counts the arrival
-// with an agent-scope atomic.  The workgroup whose add came last (told by the value the add returned) takes ONE agent-scope acquire,
+// with an agent-scope atomic.  The workgroup whose add came last (told by the value the add returned)
 // reads the records with sc1 loads, sorts them by pixel index into the caller's arrays when the order is RASTER, and puts the
 // self-cleaning counters back to zero: no separate sort launch, no clearing launch.  Called by all 256 threads of a workgroup.
 __device__ __forceinline__ void frame_arrive_and_sort(int32_t* done /* this frame's ARRIVE_WORDS */, int wg /* this workgroup's number within the frame */, int n_workgroups,
@@ -205,30 +205,51 @@ __device__ __forceinline__ void frame_arrive_and_sort(int32_t* done /* this fram
 	}
 	__syncthreads();
 	if(!*s_last) return;
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
+	// No acquire fence: every byte read below (records, indices, the counter) was stored write-through / by an L2 atomic and drained before its
+	// workgroup's arrival was counted, and is read with sc1 loads (Guideline 16, form R1: that replaces the release AND the acquire).
 	if(threadIdx.x == 0) { // self-cleaning: every workgroup of this frame has arrived
 		if(cand_count) *cand_count = 0;
 		done[ARRIVE_SHARDS * ARRIVE_LINE] = 0;
 	}
 	if(order != VP_ORDER_RASTER) return;
-	// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique)
+	// RASTER order: rank of each record = number of records with a smaller pixel index (indices are unique).  This is a serial tail of the
+	// launch (a single frame spent 6 us here: fence, counter, indices, records -- four dependent round trips), so slot t of the append-order
+	// arrays is requested together with the counter, before it is known whether the slot is in use (it is allocated either way).
+	const int t = (int)threadIdx.x;
+	const bool slot = t < max_matches;
+	const uint16_t* sp0 = reinterpret_cast<const uint16_t*>(rec_work + (size_t)(slot ? t : 0) * 22);
+	const uint32_t mine0 = ld_wt32(idx_work + (slot ? t : 0));
+	uint16_t r0[11];
+#pragma unroll
+	for(int k = 0; k < 11; k++) r0[k] = ld_wt16(sp0 + k);
 	const int nrec = min(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), max_matches);
+	if(nrec <= 256) { // one pass (the usual case: ~130 blobs per frame)
+		tile[t] = t < nrec ? mine0 : 0xFFFFFFFFu;
+		__syncthreads();
+		if(t < nrec) {
+			int rank = 0;
+			for(int j2 = 0; j2 < nrec; j2++) rank += tile[j2] < mine0;
+			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + (size_t)rank * 22);
+#pragma unroll
+			for(int k = 0; k < 11; k++) dp[k] = r0[k];
+			if(idx_sorted) idx_sorted[rank] = mine0;
+		}
+		return;
+	}
 	for(int t0 = 0; t0 < nrec; t0 += 256) {
-		const int t = t0 + (int)threadIdx.x;
-		const uint32_t mine = t < nrec ? ld_wt32(idx_work + t) : 0;
+		const int tt = t0 + t;
+		const uint32_t mine = tt < nrec ? ld_wt32(idx_work + tt) : 0;
 		int rank = 0;
 		for(int j0 = 0; j0 < nrec; j0 += 256) {
-			const int j = j0 + (int)threadIdx.x;
-			tile[threadIdx.x] = j < nrec ? ld_wt32(idx_work + j) : 0xFFFFFFFFu;
+			const int j = j0 + t;
+			tile[t] = j < nrec ? ld_wt32(idx_work + j) : 0xFFFFFFFFu;
 			__syncthreads();
 			const int m = min(256, nrec - j0);
 			for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
 			__syncthreads();
 		}
-		if(t < nrec) {
-			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + (size_t)t * 22);
+		if(tt < nrec) {
+			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + (size_t)tt * 22);
 			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + (size_t)rank * 22);
 #pragma unroll
 			for(int k = 0; k < 11; k++) dp[k] = ld_wt16(sp + k);
