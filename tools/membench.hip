@@ -40,6 +40,36 @@ void run(const uint4* in, uint4* out, int W, int H, int B, int order) {
 	printf("tile %4dx%-3d order %d B=%d: %8.1f us  %7.0f GB/s (read+write)\n", TW, TH, order, B, ms * 1e3, bytes / ms / 1e6);
 }
 
+// read-only and write-only streams of the same footprint (one 16-byte access per thread, grid-stride): what a pure consumer (the circle + blobList
+// walker reads the table once) or a pure producer can hope for
+__global__ __launch_bounds__(256) void k_read(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n16) {
+	uint4 acc = {0, 0, 0, 0};
+	for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+		typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+		const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(in) + i);
+		acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+	}
+	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = acc; // never true for the memset pattern: keeps the loads alive
+}
+__global__ __launch_bounds__(256) void k_write(uint4* __restrict__ out, size_t n16) {
+	for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+		typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+		__builtin_nontemporal_store(v4u{1, 2, 3, (unsigned)i}, reinterpret_cast<v4u*>(out) + i);
+	}
+}
+static void run_stream(const uint4* in, uint4* out, size_t bytes, int blocks_per_cu) {
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	const int grid = 256 * blocks_per_cu, N = 20;
+	for(int w = 0; w < 2; w++) {
+		for(int i = 0; i < 3; i++) { if(w) k_write<<<grid, 256>>>(out, bytes / 16); else k_read<<<grid, 256>>>(in, out, bytes / 16); }
+		CK(hipEventRecord(e0));
+		for(int i = 0; i < N; i++) { if(w) k_write<<<grid, 256>>>(out, bytes / 16); else k_read<<<grid, 256>>>(in, out, bytes / 16); }
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= N;
+		printf("%s only, %d workgroups per CU, %.0f MB: %8.1f us  %7.0f GB/s\n", w ? "write" : "read ", blocks_per_cu, bytes / 1e6, ms * 1e3, bytes / ms / 1e6);
+	}
+}
+
 int main(int argc, char** argv) {
 	const int W = 2048, H = 1536, B = argc > 1 ? atoi(argv[1]) : 32;
 	uint4 *in, *out;
@@ -53,5 +83,6 @@ int main(int argc, char** argv) {
 		run<512, 8>(in, out, W, H, B, order);
 		run<1024, 4>(in, out, W, H, B, order);
 	}
+	for(int bpc : {4, 8, 16, 32}) run_stream(in, out, n, bpc);
 	return 0;
 }
