@@ -449,7 +449,10 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 		float thr, int m_thr, float min_score, int list_radius, int max_matches, int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
-	constexpr int R = RT, PF = 4, WL = ((2 * R + 1 + PF - 1) / PF) * PF, USE = 62 - 2 * R; // USE: image columns a wavefront yields
+	// PF rows of loads in flight per lane (a walk is one dependent chain per lane).  With 4 the kernel held 7 MB in flight on the whole chip, half of
+	// what HBM latency x bandwidth asks for: 128 frames 0.379 ms; 8 and more: 0.354 (12 and 16 no better).  WL (window length, >= 2r+1) must be a
+	// multiple of PF, so PF is chosen per radius to keep the windows tight: 2r+1 itself up to 13, about half of it above.
+	constexpr int R = RT, NW = 2 * R + 1, PF = NW <= 13 ? (NW < 8 ? 8 : NW) : (NW + 1) / 2, WL = ((NW + PF - 1) / PF) * PF, USE = 62 - 2 * R; // USE: image columns a wavefront yields
 	const int lane = threadIdx.x & 63;
 	// A workgroup = 4 independent wavefronts of ONE frame (the frame's work items are padded to a multiple of 4, so that the workgroup can
 	// take part in that frame's arrival count).  XCD-aware: each XCD walks a contiguous run of workgroups (strips of one segment row are
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 		int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
-	constexpr int R = RT, O = OT, PF = 4, NB = R - 1;                        // NB: box side
-	constexpr int WFL = ((2 * O + 1 + 3) / 4) * 4;                            // own-column flat window (rows t'-o .. t'+o), a multiple of PF
+	constexpr int R = RT, O = OT, PF = 8, NB = R - 1;                        // NB: box side; PF rows of loads in flight per lane (see k_circle_walk: 4 were too few)
+	constexpr int WFL = ((2 * O + 1 + PF - 1) / PF) * PF;                     // own-column flat window (rows t'-o .. t'+o), a multiple of PF
 	constexpr int RING = ((R + 2 + WFL - 1) / WFL) * WFL;                     // ring length of the row windows: >= r+2, a multiple of WFL; the loop is unrolled RING-fold
 	constexpr int LO = R + O + 2, HI = 64 - R - O, USE = HI - LO + 1;         // lanes that report blobs: their boxes, gradientDot taps and peak-test neighbours are in the wavefront
 	static_assert(USE >= 16 && RING % WFL == 0 && WFL % PF == 0 && NB >= 1 && NB <= 11, "window geometry");
