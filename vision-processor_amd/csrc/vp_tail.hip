@@ -483,9 +483,10 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
 	const int s0 = ya - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ya - 1 at k = 2r, when the windows are full
 	const int nsteps = 2 * R + (yb - ya) + 2;
+	const int row_hi = min(h - 1, s0 + nsteps - 1 + R); // the run-ahead past the last step re-reads the segment's last row (a cache hit) instead of rows nobody needs
 #define VP_WK_ISSUE(SLOT, K)                                                                                                           \
 	do {                                                                                                                               \
-		const uint32_t soff_ = (uint32_t)vp_clampi(s0 + (K) + R, 0, h - 1) * row_bytes; /* SAT row t + r, clamp-to-edge (satBlobCenter.cl:20) */ \
+		const uint32_t soff_ = (uint32_t)vp_clampi(s0 + (K) + R, 0, row_hi) * row_bytes; /* SAT row t + r, clamp-to-edge (satBlobCenter.cl:20) */ \
 		Pe[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oe, soff_, 0);                                                             \
 	} while(0)
 #pragma unroll
@@ -598,7 +599,8 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	// the box row B(., t'), the quadrant minimum of row y = t' - r (boxes ending at rows y + r and y - 1) and tests row y - 1
 	const int f0 = ya - R - O;
 	const int nsteps = 2 * R + 2 * O + 1 + (yb - ya);
-#define VP_FW_ISSUE(SLOT, K) Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)vp_clampi(f0 + (K), 0, h - 1) * row_bytes, 0)
+	const int row_hi = min(h - 1, f0 + nsteps - 1); // the run-ahead past the last step re-reads the segment's last row (a cache hit)
+#define VP_FW_ISSUE(SLOT, K) Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)vp_clampi(f0 + (K), 0, row_hi) * row_bytes, 0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_FW_ISSUE(p, p);
 	for(int kb = 0; kb < nsteps; kb += RING) {
