@@ -16,7 +16,11 @@ ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(2024)
 pool = [cfgs.T_MID, cfgs.T_RGGB, cfgs.T_GRBG, cfgs.T_BGR, cfgs.T_RAGGED, cfgs.T_RAGGED.with_(name="t_ragged_even", qw=68, qh=46), cfgs.CFG1]
 t0, frames, launches, seed = time.time(), 0, 0, 10_000
+t_note = t0
 while time.time() - t0 < budget:
+    if time.time() - t_note > 60:  # a line a minute: a silent GPU job is taken to be hung
+        t_note = time.time()
+        print(f"... {frames} frames in {launches} launches so far, all identical", flush=True)
     cfg = pool[int(rng.integers(len(pool)))]
     mode = int(rng.integers(2))
     B = int(rng.choice([1, 1, 2, 3, 5, 17]))
