@@ -383,10 +383,11 @@ struct WalkEmit {
 	int list_radius, max_matches;
 };
 template<int R>
-__device__ __forceinline__ void walk_detect(int m_up, int m_mid, int m_dn, bool col_ok, bool x_first, bool x_last, int x, int y, int w, int h, int m_thr, int& rej,
-		const WalkEmit& em, int lane) {
-	const bool above = col_ok && m_mid >= m_thr; // blobList.cl:39
-	if(__ballot(above) == 0) return;              // wave-uniform
+__device__ __forceinline__ void walk_detect(int m_up, int m_mid, int m_dn, bool col_ok, uint64_t col_mask /* ballot of col_ok */, bool x_first, bool x_last, int x, int y, int w, int h, int m_thr,
+		int& rej, const WalkEmit& em, int lane) {
+	// blobList.cl:39 for the whole wavefront: one compare, one scalar AND with the (loop-invariant) mask of the reporting lanes, one branch
+	if((__builtin_amdgcn_ballot_w64(m_mid >= m_thr) & col_mask) == 0) return; // wave-uniform
+	const bool above = col_ok && m_mid >= m_thr;
 	const float v = walk_quot<R>(m_mid);
 	float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); // wave_shr:1: lane i <- lane i-1
 	float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); // wave_shl:1: lane i <- lane i+1
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sat_all + z * n), 0, (int)(n * 4), 0x00020000); // host: n * 4 < 2^31
 	const uint32_t row_bytes = (uint32_t)w * 4u;
 	const bool col_ok = lane >= R + 1 && lane <= 62 - R && x < w; // (x >= 0 for these lanes)
+	const uint64_t col_mask = __builtin_amdgcn_ballot_w64(col_ok);
 	const bool x_first = x == 0, x_last = x == w - 1;
 	// Windows of the last WL >= 2r+1 rows of -D1 / D2, and the raw SAT values of the next PF rows in flight: a row's load is
 	// issued PF steps before it is used (a walk is one dependent chain per lane; without the run-ahead every step would wait a full
@@ -484,10 +486,16 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	const int s0 = ya - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ya - 1 at k = 2r, when the windows are full
 	const int nsteps = 2 * R + (yb - ya) + 2;
 	const int row_hi = min(h - 1, s0 + nsteps - 1 + R); // the run-ahead past the last step re-reads the segment's last row (a cache hit) instead of rows nobody needs
+	// The scalar side of a row step is kept short on purpose (it was 19 scalar instructions against 12 vector ones and filled 61 % of the scalar
+	// issue slots): the byte offset of the next row to request runs along as ONE scalar (add, max, min: clamp-to-edge of satBlobCenter.cl:20 and
+	// the segment's last row), and "windows full and row inside the segment" is ONE unsigned range test.
+	int so_next = (s0 + R) * (int)row_bytes;            // row s0 + K + R of the K-th request (negative above the image: clamped when used)
+	const int so_hi = row_hi * (int)row_bytes;
+	const unsigned det_n = (unsigned)max(0, yb - s0 + 1 - (2 * R + 2)); // steps 2r+2 .. 2r+2+det_n-1 complete a row y = s0 + k - 1 < yb with full windows
 #define VP_WK_ISSUE(SLOT, K)                                                                                                           \
 	do {                                                                                                                               \
-		const uint32_t soff_ = (uint32_t)vp_clampi(s0 + (K) + R, 0, row_hi) * row_bytes; /* SAT row t + r, clamp-to-edge (satBlobCenter.cl:20) */ \
-		Pe[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oe, soff_, 0);                                                             \
+		Pe[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)min(max(so_next, 0), so_hi), 0); /* request number K, in order */ \
+		so_next += (int)row_bytes;                                                                                                     \
 	} while(0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_WK_ISSUE(p, p);
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 			const int t = s0 + k;
 			if(BCOUT && k >= 2 * R && t >= ya && t < yb && col_ok) bc_out[z * n + (size_t)t * w + x] = walk_quot<R>(m_dn);
 			const int y = t - 1; // the row whose four neighbours are now known
-			if(k >= 2 * R + 2 && y < yb) walk_detect<R>(m_up, m_mid, m_dn, col_ok, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			if((unsigned)(k - (2 * R + 2)) < det_n) walk_detect<R>(m_up, m_mid, m_dn, col_ok, col_mask, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
 			m_up = m_mid;
 			m_mid = m_dn;
 		}
@@ -586,6 +594,7 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	const uint32_t row_bytes = (uint32_t)w * 4u;
 	const bool g_ok = lane >= O && lane <= 63 - O && xd >= 1 && xd < w;   // gradientDot of the data column counts: inside the image, not column 0, taps in the wavefront
 	const bool col_ok = lane >= LO && lane <= HI && x < w;                 // this lane reports blobs (x >= 0 for these lanes)
+	const uint64_t col_mask = __builtin_amdgcn_ballot_w64(col_ok);
 	const bool x_first = x == 0, x_last = x == w - 1;
 	uint32_t FW[WFL], Pe[PF]; // own-column flat values of the last WFL rows; flat values of the next PF rows in flight
 	int GW[RING], BP[RING], BN[RING]; // gradientDot of the data column, B(x+2, .), B(x-r+1, .) of the last RING rows
@@ -600,7 +609,14 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	const int f0 = ya - R - O;
 	const int nsteps = 2 * R + 2 * O + 1 + (yb - ya);
 	const int row_hi = min(h - 1, f0 + nsteps - 1); // the run-ahead past the last step re-reads the segment's last row (a cache hit)
-#define VP_FW_ISSUE(SLOT, K) Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)vp_clampi(f0 + (K), 0, row_hi) * row_bytes, 0)
+	int so_next = f0 * (int)row_bytes;                  // scalar side kept short, see k_circle_walk: running byte offset of the next request ...
+	const int so_hi = row_hi * (int)row_bytes;
+	const unsigned det_n = (unsigned)max(0, yb + R + O + 1 - f0 - (2 * R + 2 * O + 1)); // ... and one range test: y = f0 + k - O - R - 1 < yb
+#define VP_FW_ISSUE(SLOT, K)                                                                                                           \
+	do {                                                                                                                               \
+		Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)min(max(so_next, 0), so_hi), 0);                   \
+		so_next += (int)row_bytes;                                                                                                     \
+	} while(0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_FW_ISSUE(p, p);
 	for(int kb = 0; kb < nsteps; kb += RING) {
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 			const int jo = (j - (R + 1) + 2 * RING) % RING;   // row t' - r - 1 = y - 1
 			const int m_dn = min(min(BP[j], BN[jo]), -max(BP[jo], BN[j])); // min(pp, nn, pn, np) of row y = t' - r (satBlobCenter.cl:37-41, times r^2)
 			const int y = tq - R - 1; // the row whose four neighbours are now known
-			if(k >= 2 * R + 2 * O + 1 && y < yb) walk_detect<R>(m_up, m_mid, m_dn, col_ok, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			if((unsigned)(k - (2 * R + 2 * O + 1)) < det_n) walk_detect<R>(m_up, m_mid, m_dn, col_ok, col_mask, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
 			m_up = m_mid;
 			m_mid = m_dn;
 		}
