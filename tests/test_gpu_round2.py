@@ -466,3 +466,46 @@ def test_tuning_knobs_are_result_neutral(env, cfg):
             ctx.tune("no_such_knob", 1)
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("r,o", [(4, 1), (5, 2), (9, 3)])
+def test_local_variant_ignores_the_alpha_byte(env, r, o):
+    """gradientDot is formed from the three colour bytes only (gradientDot.cl:25-29).  The local walker computes it with byte dot products on
+    alpha-masked pixels: a flat image with RANDOM alpha bytes must give the records of the global-table path (vp_graddot_sat + vp_blobcenter_list),
+    whose gradient code never touches byte 3, and the records of the same image with alpha = 255."""
+    capi, torch = env
+    rng = np.random.default_rng(77 + r)
+    h, w, mm, B = 200, 320, 6000, 2
+    flat = rng.integers(0, 256, (B, h, w, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(40):  # discs on noise: plenty of ring-like maxima
+        cy, cx = rng.integers(0, h), rng.integers(0, w)
+        flat[:, (yy - cy) ** 2 + (xx - cx) ** 2 <= (r + 1) ** 2, :3] = rng.integers(0, 256, 3, dtype=np.uint8)
+    opaque = flat.copy(); opaque[..., 3] = 255
+    thr = 40.0
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        def run(img, local):
+            d = dev(torch, img)
+            m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"); idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+            cnt = torch.full((B, 3), -9, dtype=torch.int32, device="cuda")
+            if local:
+                ctx.flat_bloblist(d, w, h, B, o, r, thr, 0.0, 3, mm, capi.ORDER_RASTER, m, idx, cnt)
+            else:
+                sat = torch.zeros((B, h, w), dtype=torch.int32, device="cuda")
+                ctx.graddot_sat(d, w, h, o, B, capi.SAT_TILED, sat)
+                cnt.zero_()
+                ctx.blobcenter_list(d, sat, w, h, B, r, thr, 0.0, 3, mm, capi.ORDER_RASTER, m, idx, cnt)
+            ctx.sync()
+            return cnt.cpu().numpy(), idx.cpu().numpy(), m.cpu().numpy()
+        want = run(flat, False)
+        assert int(want[0][:, 0].min()) > 5 and int(want[0][:, 0].max()) <= mm  # (beyond max_matches the kept subset is the atomics' order)
+        for got in (run(flat, True), run(opaque, True)):
+            assert np.array_equal(got[0][:, :2], want[0][:, :2]), (got[0], want[0])
+            for i in range(B):
+                n = min(int(want[0][i, 0]), mm)
+                assert np.array_equal(got[1][i, :n], want[1][i, :n])
+                # the record's colour / centre fields come from flat itself (alpha is not part of a record): compare everything
+                assert got[2][i, :22 * n].tobytes() == want[2][i, :22 * n].tobytes()
+    finally:
+        ctx.close()

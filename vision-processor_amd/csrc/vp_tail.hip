@@ -623,14 +623,14 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 #pragma unroll
 		for(int j = 0; j < RING; j++) {
 			const int k = kb + j;
-			const uint32_t e = Pe[j % PF];
+			const uint32_t e = Pe[j % PF] & 0x00FFFFFFu; // colour bytes only (grad_dot_u8)
 			VP_FW_ISSUE(j % PF, k + PF);
 			FW[j % WFL] = e;
 			const int tq = f0 + k - O; // gradientDot / box row t'
 			{
 				const uint32_t c = FW[(j - O + 2 * WFL) % WFL], yn = FW[(j - 2 * O + 2 * WFL) % WFL]; // flat(xd, t'), flat(xd, t' - o); e = flat(xd, t' + o)
 				const uint32_t xp = (uint32_t)__builtin_amdgcn_ds_bpermute(a_fp, (int)c), xn = (uint32_t)__builtin_amdgcn_ds_bpermute(a_fn, (int)c);
-				int g = grad_dot_pk(xp, xn, e, yn); // gradientDot.cl:25-29
+				int g = grad_dot_u8(xp, xn, e, yn); // gradientDot.cl:25-29
 				if(!(g_ok && k >= 2 * O && tq >= 1 && tq < h)) g = 0; // outside the image, row 0 and column 0 contribute nothing (see above)
 				V += g - GW[(j - NB + 2 * RING) % RING]; // the value from r-1 rows ago leaves the window
 				GW[j] = g;
