@@ -235,24 +235,95 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
     return out
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, timeout_s=1500.0):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not imported torch nor touched a
-    GPU), relay rank 0's stdout, wait for all, exit with the worst return code."""
+    GPU), relay rank 0's JSON line.  All children are polled: the first one that exits non-zero (a bad device, an OOM, an assertion)
+    ends the others at once instead of leaving them in a rendezvous or a barrier until the collective's own timeout, and its stderr
+    tail is what the caller sees; an overall timeout bounds the whole run.  Only the exact PIDs started here are ever signalled."""
     import socket
+    import tempfile
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    for line in out0.splitlines():  # exactly the JSON line goes to stdout; library chatter (e.g. gloo's connection notes) to stderr
+        logs.append(tempfile.TemporaryFile())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=logs[r]))
+
+    def tail(f, lines=40):
+        f.seek(0)
+        return "\n".join(f.read().decode(errors="replace").splitlines()[-lines:])
+
+    t0, failed = time.time(), None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = (bad[0], f"rank {bad[0]} exited with code {rcs[bad[0]]}")
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() - t0 > timeout_s:
+            failed = (next(r for r, rc in enumerate(rcs) if rc is None), f"no result after {timeout_s:.0f} s")
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:  # the ranks this function started, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        r, why = failed
+        sys.stderr.write(f"bench.py --gpus {n}: {why}; the other ranks were stopped.  stderr of rank {r}:\n{tail(logs[r])}\n")
+        return 1
+    for r in range(n):  # library chatter of every rank, prefixed
+        for line in tail(logs[r], 20).splitlines():
+            sys.stderr.write(f"[rank {r}] {line}\n")
+    out0.seek(0)
+    for line in out0.read().decode().splitlines():  # exactly the JSON line goes to stdout; anything else rank 0 printed goes to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return 0
+
+
+def verify_against_oracle(cfg, raws, frames, flat, sat, matches, idx, counter, mm):
+    """The timed launch checked against the CPU oracle (the checker, never the measured path): the given frames of the LAST timed step --
+    flat, the int32 SAT, counters, raster-sorted pixel indices and the 22-byte records -- byte for byte.  Returns the `verified` object of
+    the bench line; a mismatch makes bench.py exit non-zero instead of printing a number."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    port = O.Port(threads=host_cores())
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    scratch = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+    bad = []
+    for k in frames:
+        m, widx, cnt = port.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                  cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=scratch)
+        if not np.array_equal(flat[k].cpu().numpy(), scratch["flat"]):
+            bad.append((k, "flat"))
+        if sat is not None:
+            wsat, mx = port.sat_i32(scratch["graddot"])
+            if mx >= 2 ** 24 or not np.array_equal(sat[k].cpu().numpy(), wsat):
+                bad.append((k, "sat"))
+        c = counter[k].cpu().numpy()
+        if not np.array_equal(c, cnt):
+            bad.append((k, f"counter {c.tolist()} != {cnt.tolist()}"))
+            continue
+        n = min(int(c[0]), mm)
+        if not np.array_equal(idx[k].cpu().numpy().view(np.uint32)[:n], widx):
+            bad.append((k, "pixel indices"))
+        if matches[k].cpu().numpy()[:22 * n].tobytes() != m.tobytes():
+            bad.append((k, "records"))
+    return {"frames": [int(k) for k in frames], "ok": not bad, "against": "oracle/vp_oracle.c (CPU checker) on the same sensor frames: flat, int32 SAT, counters, sorted pixel indices, 22-byte records, byte for byte",
+            "mismatches": [f"frame {k}: {what}" for k, what in bad]}
 
 
 def cpu_baseline(cfg, seconds, opencl):
@@ -327,6 +398,7 @@ def main():
     ap.add_argument("--detect-threads", type=int, default=0, help="host threads of the CPU stage (0 = this rank's share of the cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements taken after the headline region (batch sweep, single-frame latency, "
                     "streams in flight, PCIe-inclusive rate); they run at N = 1 only and never enter `value`")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of two frames of the last timed step with the CPU oracle (rank 0, after the timed region)")
     ap.add_argument("--opencl-probe", action="store_true", help="print the OpenCL platform / device report as JSON and exit (used as a child process)")
     args = ap.parse_args()
     if args.opencl_probe:
@@ -494,6 +566,7 @@ def main():
         elapsed = float(t.item())
 
     coll = "gloo (one-GPU rehearsal)" if rehearse else "RCCL"
+    failed = False
     if rank == 0:
         cnt = cnt_now
         if args.sat == "local":  # no SAT pass exists: the fused kernel reads flat once (4 B/px algorithmic)
@@ -548,17 +621,25 @@ def main():
                 out["detect"]["gathered_packets"] = sum(1 for r in allp for p in r if p)
                 assert allp[0] == mine
             out["config"]["sharding"] = f"{world} x {B} independent feeds" + (f", {coll} all-gather of SSL_WrapperPackets per step" if dist else "")
+        if not args.no_verify:
+            # what the timed steps left in the buffers (before the extra measurements reuse them), held to the CPU oracle
+            vm, vc = (det["m"][(step_no[0] - 1) & 1], det["c"][(step_no[0] - 1) & 1]) if det is not None else (matches, counter)
+            out["verified"] = verify_against_oracle(cfg, raws, sorted({0, B - 1}), flat, sat, vm, idx, vc, mm)
         if world == 1 and not args.no_extras and det is None and sat is not None:
             out["extras"] = extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, counter, idx, B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, opencl)
             out["opencl"] = opencl
-        print(json.dumps(out), flush=True)
+        if out.get("verified") and not out["verified"]["ok"]:
+            sys.stderr.write("bench.py: the timed launch does NOT match the CPU oracle: " + "; ".join(out["verified"]["mismatches"]) + "\n")
+            failed = True
+        else:
+            print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
-    return 0
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":

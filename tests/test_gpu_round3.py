@@ -1,0 +1,207 @@
+"""GPU parity tests added in round 3, all through the C ABI.
+
+  * THE LAUNCH bench.py TIMES: cfg2 (2048x1536 RGGB) x 128 distinct frames in one vp_frame call with the bench's exact parameters
+    (VP_SAT_TILED, RASTER order, coordinate map, the adopted torch stream, the feed seeds of feeds.py) -- frames 0, 15, 16, 17 and 127
+    (both ends and both sides of a 16-frame resampling group) byte for byte against the CPU oracle: flat, the int32 SAT, counters,
+    sorted records; ALL 128 frames through size-independent properties: the SAT equals the 64-bit 2-D cumulative sum of gradientDot
+    formed from the kernel's own flat by plain torch integer arithmetic, flat equals what the unstaged per-pixel resampling kernel
+    gives, and VP_SAT_LOCAL's records equal VP_SAT_TILED's.  Call sequence replaced: Resources.cpp:151-164 + main.cpp:283-317.
+  * BASELINE configs[2] AT ITS OWN SIZE: the same 2048x1536 frames as 8 streams x 8 frames, every stream loaded before anything is
+    waited for, three rounds: every stream's flat / SAT / counters / records equal the one-launch result byte for byte, and one frame
+    per stream equals the oracle (one loop per camera: main.cpp:262-317).
+"""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+CFG = cfgs.CFG2
+B_BENCH = 128          # bench.py --batch default
+ORACLE_FRAMES = (0, 15, 16, 17, 127)
+NS, PER = 8, 8         # configs[2]: 8 streams x 8 frames in flight
+STREAM_ORACLE = {s: s * PER + (3 * s) % PER for s in range(NS)}  # one oracle-checked frame per stream
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return cases.vp.load_capi(), torch
+
+
+@pytest.fixture(scope="module")
+def bench_frames():
+    """The 128 synthetic sensor frames bench.py uploads on rank 0 (feed_seed(0, i)); rendered on host threads (ctypes releases the GIL)."""
+    seeds = [cases.vp.feeds.feed_seed(0, i) for i in range(B_BENCH)]
+    with ThreadPoolExecutor(16) as ex:
+        return np.stack(list(ex.map(CFG.synth, seeds)))
+
+
+@pytest.fixture(scope="module")
+def oracle_of(bench_frames):
+    """frame index -> the CPU oracle's flat, int32 SAT, counters and raster-sorted records for that frame (cached across the tests)."""
+    big = O.Port(threads=min(16, os.cpu_count() or 1))
+    model = O.CameraModel.from_array(np.frombuffer(bytes(CFG.model()), np.uint8))
+    cache = {}
+
+    def get(i):
+        if i not in cache:
+            mm = CFG.max_matches
+            s = big.frame_scratch(CFG.qw, CFG.qh, CFG.fw, CFG.fh, mm)
+            m, idx, cnt = big.frame(bench_frames[i], CFG.layout, CFG.qw, CFG.qh, model, CFG.max_robot_height, CFG.field_scale, CFG.off_x, CFG.off_y, CFG.sampler_mode,
+                                    CFG.fw, CFG.fh, CFG.grad_offset, CFG.circle_radius, CFG.list_radius, CFG.circ_threshold, CFG.min_score, mm, scratch=s)
+            sat, mx = big.sat_i32(s["graddot"])
+            assert mx < 2 ** 24, "benchmark inputs must satisfy the 2^24 exactness guard (SURVEY H2)"
+            assert 80 <= len(m) <= mm
+            cache[i] = dict(flat=s["flat"].copy(), sat=sat, m=m, idx=idx, cnt=cnt)
+        return cache[i]
+    return get
+
+
+def alloc(torch, n, with_sat=True):
+    mm = CFG.max_matches
+    return dict(flat=torch.zeros((n, CFG.fh, CFG.fw, 4), dtype=torch.uint8, device="cuda"),
+                sat=torch.zeros((n, CFG.fh, CFG.fw), dtype=torch.int32, device="cuda") if with_sat else None,
+                m=torch.zeros((n, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((n, mm), dtype=torch.int32, device="cuda"),
+                cnt=torch.full((n, 3), -5, dtype=torch.int32, device="cuda"))
+
+
+def assert_frame_is_the_oracles(capi, torch, bufs, k, want, what, with_sat=True):
+    mm = CFG.max_matches
+    assert torch.equal(bufs["flat"][k].cpu(), torch.from_numpy(want["flat"])), (what, "flat")
+    if with_sat:
+        assert torch.equal(bufs["sat"][k].cpu(), torch.from_numpy(want["sat"])), (what, "sat")
+    cnt = bufs["cnt"][k].cpu().numpy()
+    assert np.array_equal(cnt, want["cnt"]), (what, cnt, want["cnt"])
+    n = min(int(cnt[0]), mm)
+    assert np.array_equal(bufs["idx"][k].cpu().numpy().view(np.uint32)[:n], want["idx"]), (what, "RASTER order = sorted pixel indices")
+    assert bufs["m"][k].cpu().numpy()[:22 * n].tobytes() == want["m"].tobytes(), (what, "records")
+
+
+def torch_sat_reference(torch, flat, o):
+    """gradientDot.cl:22-30 + satHorizontal.cl / satVertical.cl:22-32 on a (n, h, w, 4) uint8 device tensor in plain torch integer
+    arithmetic: clamp-to-edge taps at distance o, sum over the three colour channels of gx * gy, 64-bit cumulative sums, wrapped to int32."""
+    n, h, w, _ = flat.shape
+    c = flat[..., :3].to(torch.int32)
+    xs, ys = torch.arange(w, device=flat.device), torch.arange(h, device=flat.device)
+    gx = c[:, :, (xs + o).clamp(max=w - 1)] - c[:, :, (xs - o).clamp(min=0)]
+    gy = c[:, (ys + o).clamp(max=h - 1)] - c[:, (ys - o).clamp(min=0)]
+    gd = (gx * gy).sum(-1).to(torch.int64)
+    full = gd.cumsum(1).cumsum(2)
+    assert int(full.abs().max()) < 2 ** 24
+    return full.to(torch.int32)
+
+
+def test_the_timed_launch_against_the_oracle(env, bench_frames, oracle_of):
+    capi, torch = env
+    B, mm = B_BENCH, CFG.max_matches
+    ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)  # as bench.py: the adopted torch stream
+    try:
+        d_raw = dev(torch, bench_frames)
+        tiled = alloc(torch, B)
+        p = capi.frame_params(CFG, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)  # bench.py defaults (use_coord_map = 1)
+        for _ in range(3):  # warm-up + steps: epochs, tickets, the cached map and the self-cleaning counters are reused as in the timed loop
+            ctx.frame(p, d_raw, B, tiled["flat"], tiled["sat"], tiled["m"], tiled["cnt"], idx=tiled["idx"])
+        ctx.sync()
+        for k in ORACLE_FRAMES:
+            assert_frame_is_the_oracles(capi, torch, tiled, k, oracle_of(k), ("tiled", k))
+        # every frame: SAT == cumulative sums of gradientDot of the kernel's own flat; flat == the per-pixel (unstaged, unmapped) resampling kernel
+        model = CFG.model()
+        other = torch.empty((8, CFG.fh, CFG.fw, 4), dtype=torch.uint8, device="cuda")
+        for k0 in range(0, B, 8):
+            want = torch_sat_reference(torch, tiled["flat"][k0:k0 + 8], CFG.grad_offset)
+            assert torch.equal(tiled["sat"][k0:k0 + 8], want), ("SAT property", k0)
+            ctx.resample_raw(d_raw[k0:k0 + 8], CFG.layout, CFG.qw, CFG.qh, model, CFG.max_robot_height, CFG.field_scale, CFG.off_x, CFG.off_y, CFG.sampler_mode, CFG.fw, CFG.fh, 8, other)
+            ctx.sync()
+            assert torch.equal(tiled["flat"][k0:k0 + 8], other), ("flat: staged+mapped vs per-pixel kernel", k0)
+        cnt = tiled["cnt"].cpu().numpy()
+        assert int(cnt[:, 0].min()) >= 80 and int(cnt[:, 0].max()) <= mm
+        # the same launch without a global table
+        local = alloc(torch, B, with_sat=False)
+        local["flat"] = tiled["flat"]  # resampling rewrites it with the same bytes
+        pl = capi.frame_params(CFG, sat_variant=capi.SAT_LOCAL, order=capi.ORDER_RASTER)
+        for _ in range(2):
+            ctx.frame(pl, d_raw, B, local["flat"], None, local["m"], local["cnt"], idx=local["idx"])
+        ctx.sync()
+        for k in ORACLE_FRAMES:
+            assert_frame_is_the_oracles(capi, torch, local, k, oracle_of(k), ("local", k), with_sat=False)
+        assert torch.equal(local["cnt"], tiled["cnt"])
+        lm, li, tm, ti = local["m"].cpu().numpy(), local["idx"].cpu().numpy(), tiled["m"].cpu().numpy(), tiled["idx"].cpu().numpy()
+        for k in range(B):
+            n = min(int(cnt[k, 0]), mm)
+            assert np.array_equal(li[k, :n], ti[k, :n]) and lm[k, :22 * n].tobytes() == tm[k, :22 * n].tobytes(), ("LOCAL records == TILED records", k)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["tiled", "local"])
+def test_config2_eight_streams_by_eight_frames_at_2048x1536(env, bench_frames, oracle_of, variant):
+    capi, torch = env
+    mm = CFG.max_matches
+    with_sat = variant == "tiled"
+    p = capi.frame_params(CFG, sat_variant=capi.SAT_TILED if with_sat else capi.SAT_LOCAL, order=capi.ORDER_RASTER)
+    d_raw = dev(torch, bench_frames[:NS * PER])
+    ctx = capi.Context(0, n_streams=NS)
+    try:
+        # one launch of all 64 frames on one stream: what the streams' results are held to
+        one = alloc(torch, NS * PER, with_sat)
+        torch.cuda.synchronize()
+        ctx.frame(p, d_raw, NS * PER, one["flat"], one["sat"], one["m"], one["cnt"], idx=one["idx"], stream=0)
+        ctx.sync()
+        bufs = [alloc(torch, PER, with_sat) for _ in range(NS)]
+        torch.cuda.synchronize()
+        for rnd in range(3):
+            for s in range(NS):  # all eight streams are loaded before any of them is waited for
+                b = bufs[s]
+                ctx.frame(p, d_raw[s * PER:(s + 1) * PER], PER, b["flat"], b["sat"], b["m"], b["cnt"], idx=b["idx"], stream=s)
+        ctx.sync()
+        cnt1 = one["cnt"].cpu().numpy()
+        for s in range(NS):
+            b, sl = bufs[s], slice(s * PER, (s + 1) * PER)
+            assert torch.equal(b["flat"], one["flat"][sl]), (s, "flat")
+            if with_sat:
+                assert torch.equal(b["sat"], one["sat"][sl]), (s, "sat")
+            assert torch.equal(b["cnt"], one["cnt"][sl]), (s, "counters")
+            bm, bi, om, oi = b["m"].cpu().numpy(), b["idx"].cpu().numpy(), one["m"][sl].cpu().numpy(), one["idx"][sl].cpu().numpy()
+            for k in range(PER):
+                n = min(int(cnt1[s * PER + k, 0]), mm)
+                assert np.array_equal(bi[k, :n], oi[k, :n]) and bm[k, :22 * n].tobytes() == om[k, :22 * n].tobytes(), (s, k, "records")
+            g = STREAM_ORACLE[s]
+            assert_frame_is_the_oracles(capi, torch, b, g - s * PER, oracle_of(g), (variant, "stream", s, "frame", g), with_sat=with_sat)
+    finally:
+        ctx.close()
+
+
+def test_dpp_primitives_on_the_device():
+    """tools/dbg/dpp_test (built by `make dbg`): the cross-lane primitives the walkers are made of, on the real device.  Rows 0-7 (wave / row
+    shifts, ds_bpermute) must behave as documented.  Rows 8-10 are subtractions with a DPP-shifted operand: `shr(e) - a` (shifted value as
+    minuend, the only form the kernels use) must be right; `a - shl(e)` is where ROCm 7.2 / gfx950 was found to fold the shift into
+    v_subrev_u32_dpp and shift the wrong operand -- reported, not required, so that the workaround is re-examined when the toolchain changes."""
+    exe = os.path.join(cases.ROOT, "tools", "dbg", "dpp_test")
+    if not os.path.exists(exe):
+        pytest.skip("tools/dbg/dpp_test not built (make dbg)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert out.returncode == 0, out.stderr
+    rows = {ln.rsplit(":", 1)[0].strip(): [int(v) for v in ln.rsplit(":", 1)[1].split()] for ln in out.stdout.strip().splitlines()}
+    e = [100 + i for i in range(64)]
+    a = [10000 + 100 * i for i in range(64)]
+    assert rows["wave_shl:1"][:63] == e[1:] and rows["wave_shr:1"][1:] == e[:63]
+    assert rows["bperm +5 (folded)"] == [e[(i + 5) % 64] for i in range(64)] and rows["bperm -5"] == [e[(i - 5) % 64] for i in range(64)]
+    assert rows["bperm +5 (opaque)"] == [e[(i + 5) % 64] for i in range(64)]
+    assert rows["wave_rol:1"] == [e[(i + 1) % 64] for i in range(64)]
+    for r0 in range(0, 64, 16):
+        assert rows["row_shl:1"][r0:r0 + 15] == e[r0 + 1:r0 + 16] and rows["row_shr:1"][r0 + 1:r0 + 16] == e[r0:r0 + 15]
+    assert rows["shr(e) - a"][1:] == [e[i - 1] - a[i] for i in range(1, 64)], "shifted value as MINUEND: the form the kernels rely on"
+    good = rows["a - shl(e)"][:63] == [a[i] - e[i + 1] for i in range(63)]
+    print("a - shl(e) folded correctly by this toolchain:", good)

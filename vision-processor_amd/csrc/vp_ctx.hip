@@ -158,6 +158,7 @@ int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out,
 	if(grew) *grew = false;
 	if(w.bytes < bytes) {
 		if(grew) *grew = true;
+		VP_CHECK_HIP(hipSetDevice(ctx->device)); // hipMalloc / hipFree act on the current device, which a multi-context caller may have moved
 		VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
 		if(w.ptr) VP_CHECK_HIP(hipFree(w.ptr));
 		w.ptr = nullptr;

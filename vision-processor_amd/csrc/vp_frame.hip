@@ -15,6 +15,7 @@ int vp_sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w,
 		int32_t* zero3, bool* zeroed);
 int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float thr, float min_score, int radius,
 		int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter);
+bool vp_flat_walk_supported(int r, int o);
 int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
 		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed);
 
@@ -24,6 +25,17 @@ extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, cons
 	const bool local = p->sat_variant == VP_SAT_LOCAL;
 	VP_REQUIRE(b->flat && (b->sat || local) && b->matches && b->counter, "vp_frame: flat, sat, matches and counter buffers are required");
 	VP_REQUIRE(!local || (!b->sat && !b->graddot && !b->blobcenter), "vp_frame: VP_SAT_LOCAL builds no global table: sat, graddot and blobcenter must be NULL");
+	// every argument is checked before a workspace is sized from it or a kernel is enqueued: a refused call leaves the caller's buffers untouched
+	VP_REQUIRE(p->qw > 0 && p->qh > 0 && p->fw > 0 && p->fh > 0 && batch > 0 && batch <= 65535 && p->grad_offset >= 0 && p->list_radius >= 0 && p->circle_radius >= 0 && p->max_matches > 0 &&
+			(size_t)p->fw * p->fh < (size_t(1) << 31), "vp_frame: bad shape");
+	VP_REQUIRE(p->layout >= VP_LAYOUT_RGGB && p->layout <= VP_LAYOUT_BGR, "vp_frame: bad layout %d", p->layout);
+	VP_REQUIRE(p->sampler_mode == VP_SAMPLER_NEAREST || p->sampler_mode == VP_SAMPLER_BILINEAR_RTZ, "vp_frame: bad sampler mode %d", p->sampler_mode);
+	VP_REQUIRE(p->sat_variant >= VP_SAT_TILED && p->sat_variant <= VP_SAT_LOCAL, "vp_frame: bad SAT variant %d", p->sat_variant);
+	VP_REQUIRE(p->order == VP_ORDER_ATOMIC || p->order == VP_ORDER_RASTER, "vp_frame: bad order");
+	VP_REQUIRE((reinterpret_cast<uintptr_t>(b->matches) & 1) == 0, "vp_frame: matches must be 2-byte aligned");
+	VP_REQUIRE(!local || vp_flat_walk_supported(p->circle_radius, p->grad_offset), "vp_frame: VP_SAT_LOCAL has no kernel for circle radius %d with gradient offset %d", p->circle_radius, p->grad_offset);
+	// the workspaces below are allocated on the CURRENT device: a caller driving several contexts from one thread (host/feeds_multi.cpp) must land on ours
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	// halo strips for the single-pass SAT: written by whichever resampling kernel produces flat (6 % of flat, saves the SAT
 	// kernel a 128-byte line per row and side of every tile)
 	VpStrips strips = vp_make_strips(nullptr, 64, 1, 1);
@@ -55,9 +67,6 @@ extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, cons
 	} else {
 		VP_TRY(vp_resample_impl(ctx, stream, raw, true, p->layout, p->qw, p->qh, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->sampler_mode, p->fw, p->fh, batch, b->flat, strips));
 	}
-	VP_REQUIRE(p->fw > 0 && p->fh > 0 && batch > 0 && batch <= 65535 && p->list_radius >= 0 && p->circle_radius >= 0 && p->max_matches > 0 && (size_t)p->fw * p->fh < (size_t(1) << 31), "vp_frame: bad shape");
-	VP_REQUIRE(p->order == VP_ORDER_ATOMIC || p->order == VP_ORDER_RASTER, "vp_frame: bad order");
-	VP_REQUIRE((reinterpret_cast<uintptr_t>(b->matches) & 1) == 0, "vp_frame: matches must be 2-byte aligned");
 	if(local) { // resampling -> [gradientDot + local table + circle + blobList]
 		VpStageTimer t(ctx, stream, "gradientDot+satBlobCenter+blobList (local)");
 		return vp_flat_bloblist_impl(ctx, stream, b->flat, p->fw, p->fh, batch, p->grad_offset, p->circle_radius, p->circ_threshold, p->min_score, p->list_radius, p->max_matches, p->order,

@@ -655,10 +655,22 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 }
 
 // flat -> blob list with no global table (VP_SAT_LOCAL).  (r, o) pairs: every pair ceil(20 / fs), ceil(25 / fs) / 3 can form for r = 2 .. 12.
+// the (circle radius, gradient offset) pairs k_flat_walk is instantiated for (the VP_FW list below)
+bool vp_flat_walk_supported(int r, int o) {
+	static const int pairs[][2] = {{2, 1}, {3, 1}, {4, 1}, {5, 2}, {6, 2}, {7, 2}, {7, 3}, {8, 3}, {9, 3}, {9, 4}, {10, 4}, {11, 4}, {12, 4}};
+	for(const auto& p : pairs)
+		if(p[0] == r && p[1] == o) return true;
+	return false;
+}
+
 int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float thr, float min_score, int radius,
 		int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter) {
 	hipStream_t s = ctx->streams[stream];
+	// every argument is checked before anything is enqueued: a refused call leaves the caller's counters and records untouched
 	VP_REQUIRE((size_t)w * h * 4 < 0x7fffffffu, "VP_SAT_LOCAL: frame too large");
+	VP_REQUIRE(vp_flat_walk_supported(circle_radius, grad_offset), "VP_SAT_LOCAL: no kernel for circle radius %d with gradient offset %d (the pairs real geometries form are built: r 2..12 with o = ceil(25 / fs) / 3)", circle_radius, grad_offset);
+	const int use = 63 - 2 * (circle_radius + grad_offset);
+	VP_REQUIRE(use >= 16, "VP_SAT_LOCAL: circle radius %d + gradient offset %d too large for a wavefront strip", circle_radius, grad_offset);
 	ListScratch ws;
 	VP_TRY(list_scratch(ctx, stream, batch, max_matches, &ws));
 	k_zero<<<vp_div_up(3 * batch, 256), 256, 0, s>>>(counter, 3 * batch); // main.cpp:283-288
@@ -666,8 +678,6 @@ int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w
 	const bool raster = order == VP_ORDER_RASTER;
 	uint32_t* idx_work = (raster || !idx) ? ws.idx : idx;
 	uint8_t* rec_work = raster ? ws.rec_tmp : reinterpret_cast<uint8_t*>(matches);
-	const int use = 63 - 2 * (circle_radius + grad_offset);
-	VP_REQUIRE(use >= 16, "VP_SAT_LOCAL: circle radius %d + gradient offset %d too large for a wavefront strip", circle_radius, grad_offset);
 	const int strips_x = (int)vp_div_up(w, use);
 	int seg_h = ctx->tune.tail_segment_rows;
 	if(seg_h <= 0) {
