@@ -398,6 +398,7 @@ def main():
     ap.add_argument("--detect-threads", type=int, default=0, help="host threads of the CPU stage (0 = this rank's share of the cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements taken after the headline region (batch sweep, single-frame latency, "
                     "streams in flight, PCIe-inclusive rate); they run at N = 1 only and never enter `value`")
+    ap.add_argument("--plain-alloc", action="store_true", help="frame buffers from plain hipMalloc (no placement check): the allocation lottery of DESIGN.md section 4")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of two frames of the last timed step with the CPU oracle (rank 0, after the timed region)")
     ap.add_argument("--opencl-probe", action="store_true", help="print the OpenCL platform / device report as JSON and exit (used as a child process)")
     args = ap.parse_args()
@@ -447,15 +448,16 @@ def main():
     feeds = vp.feeds
     raws = np.stack([cfg.synth(feeds.feed_seed(rank, i)) for i in range(B)])
     d_raw = torch.from_numpy(raws).cuda()
-    flat = torch.empty((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
-    sat = torch.empty((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda") if args.sat != "local" else None
+    # every buffer vp_frame writes comes from the library's allocator, as a deployment's would: allocated once, the table and flat from
+    # placement-checked blocks (vp_frame_buffers_create; --plain-alloc: take what hipMalloc gives, the round-2 behaviour)
+    if args.plain_alloc:
+        ctx.tune("placement_candidates", 0)
+    slab = ctx.frame_slab(params, B)
+    flat, sat, matches, idx, counter = slab.torch_views()
     # one fixed-size detection record per frame: [counter 3 x i32 | pad 4 | matches mm x 22 | idx mm x u32]
     rec_bytes = feeds.record_bytes(mm)
     record = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]  # double-buffered: the gather of step k overlaps step k+1
     # vp_frame wants separate dense arrays; the record tensor is filled by three strided device copies per step
-    matches = torch.zeros((B, 22 * mm), dtype=torch.uint8, device="cuda")
-    idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
-    counter = torch.zeros((B, 3), dtype=torch.int32, device="cuda")
     gathered = [torch.empty((world, B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if dist else None
     pending = [None, None]
     step_no = [0]
@@ -594,6 +596,7 @@ def main():
                          "kernel": roof_kernel, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},
             "stage_ms_per_step": {k: round(float(np.mean(v)), 4) for k, v in stage_ms.items()},
             "blobs_per_frame": float(np.minimum(cnt[:, 0], mm).mean()),
+            "placement": dict(slab.placement, note="zero-fill GB/s of the blocks vp_frame_buffers_create kept for the table and flat, of the candidates it probed"),
         }
         # every stage against the same HBM roofline, on its own algorithmic bytes per flat pixel: raw sensor byte + flat
         # written (resampling), flat read + table written (SAT pass), table read (circle + blobList), flat read (local variant)
@@ -638,6 +641,8 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    del flat, sat, matches, idx, counter
+    slab.destroy()
     ctx.close()
     return 1 if failed else 0
 

@@ -90,7 +90,8 @@ const char* vp_device_name(VpContext* ctx);
  *   "sat_workgroups_per_cu" 2..8 (0 = automatic, the default), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_float_stage" 0 / 1 (default 1),
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
- *   write the dense halo strips the tiled SAT pass reads).  Applies to launches issued after the call. */
+ *   write the dense halo strips the tiled SAT pass reads), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
+ *   request; 0 or 1 = take what hipMalloc gives).  Applies to calls issued after it. */
 int vp_ctx_tune(VpContext* ctx, const char* key, int value);
 
 /* per-launch timing, the analogue of the stored cl::Event list (opencl.h:84, opencl.cpp:94-105).  When enabled every
@@ -107,6 +108,22 @@ int vp_malloc_device(VpContext* ctx, size_t bytes, void** dptr);
 int vp_free_device(VpContext* ctx, void* dptr);
 int vp_malloc_host(VpContext* ctx, size_t bytes, void** hptr);
 int vp_free_host(VpContext* ctx, void* hptr);
+/* Placement probe: mean microseconds over `reps` launches (after one untimed) of a pure 16-byte-per-lane read stream (write = 0) or zero-fill
+ * stream (write = 1: the contents are lost) over [ptr, ptr + bytes); ptr 16-byte aligned.  Synchronises the stream. */
+int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us);
+/* Placement-checked device memory.  On MI355X a large hipMalloc block takes write streams at one of two rates for as long as it lives (4.95-5.4 or
+ * 3.8-4.4 TB/s zero-fill; reads are not affected), decided by where the allocation landed.  The reference allocates its images once and keeps them
+ * (OpenCL::acquire pool, opencl.cpp:108-122; CLArray, opencl.cpp:137-159), so the draw is made once: vp_malloc_device_placed allocates up to
+ * "placement_candidates" (vp_ctx_tune, default 48) blocks without freeing, times a zero-fill of each (vp_probe_stream), hands out the `count`
+ * fastest (dptrs[0] the fastest) and frees the rest; it stops early once `count` blocks reach the fast rate and never holds more than half of the
+ * free device memory.  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
+typedef struct {
+	float write_gbs;            /* zero-fill rate of this block, GB/s (0 when nothing was probed) */
+	float best_gbs, worst_gbs;  /* over the candidates probed for the request */
+	int32_t candidates;         /* blocks allocated and probed */
+	int32_t selected;           /* 1 = chosen among candidates, 0 = plain hipMalloc */
+} VpPlacement;
+int vp_malloc_device_placed(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info /* count entries, or NULL */);
 int vp_copy_h2d(VpContext* ctx, int stream, void* dst_d, const void* src_h, size_t bytes);
 int vp_copy_d2h(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes);
 int vp_copy_d2h_sync(VpContext* ctx, int stream, void* dst_h, const void* src_d, size_t bytes);
@@ -271,6 +288,16 @@ typedef struct {
 	float* graddot;       /* optional debug view (main.cpp:291-295, 377-394) */
 	float* blobcenter;    /* optional debug view / blob_benchmark input (blob_benchmark.cpp:162) */
 } VpFrameBuffers;
+
+/* Every buffer vp_frame writes for `batch` frames of this geometry, allocated once like the reference's image pool and CLArrays (opencl.cpp:108-122,
+ * main.cpp:257-258): flat, the table (none with VP_SAT_LOCAL), matches, idx, counter, plus the optional views named in `views`.  The table and flat
+ * -- the two image-sized buffers written every frame -- come from vp_malloc_device_placed (the fastest-writing block becomes the table).
+ * vp_frame_buffers_placement reports what was drawn; vp_frame_buffers_destroy waits for the context's streams and frees everything. */
+typedef struct VpFrameSlab VpFrameSlab;
+typedef enum { VP_VIEW_PLANES = 1, VP_VIEW_GRADDOT = 2, VP_VIEW_BLOBCENTER = 4 } VpFrameViews;
+int vp_frame_buffers_create(VpContext* ctx, const VpFrameParams* params, int batch, int views, VpFrameBuffers* buffers, VpFrameSlab** slab);
+int vp_frame_buffers_placement(const VpFrameSlab* slab, VpPlacement* sat, VpPlacement* flat);
+int vp_frame_buffers_destroy(VpContext* ctx, VpFrameSlab* slab);
 
 /* raw -> blob list for `batch` frames on one stream, no host synchronisation inside. */
 int vp_frame(VpContext* ctx, int stream, const VpFrameParams* params, const uint8_t* raw, int batch, const VpFrameBuffers* buffers);

@@ -205,3 +205,60 @@ def test_dpp_primitives_on_the_device():
     assert rows["shr(e) - a"][1:] == [e[i - 1] - a[i] for i in range(1, 64)], "shifted value as MINUEND: the form the kernels rely on"
     good = rows["a - shl(e)"][:63] == [a[i] - e[i + 1] for i in range(63)]
     print("a - shl(e) folded correctly by this toolchain:", good)
+
+
+def test_frame_buffers_allocator(env, port):
+    """vp_frame_buffers_create / vp_malloc_device_placed (include/vp_hip.h): the buffers the reference allocates once (OpenCL::acquire pool,
+    opencl.cpp:108-122; CLArrays of main.cpp:257-258) from the library, the two image-sized ones from placement-checked blocks.  Small frames:
+    plain blocks, results the oracle's, the optional views present; bench-sized frames: candidates are probed, the table gets the fastest block."""
+    import ctypes as C
+    capi, torch = env
+    cfg = cfgs.T_MID
+    B, mm = 3, cfg.max_matches
+    raws = np.stack([cfg.synth(300 + i) for i in range(B)])
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
+        slab = ctx.frame_slab(p, B, views=capi.VIEW_GRADDOT | capi.VIEW_BLOBCENTER | capi.VIEW_PLANES)
+        assert slab.placement["sat"]["selected"] is False and slab.placement["sat"]["candidates"] == 2  # 3 MB blocks: nothing to choose
+        assert slab.b.planes and slab.b.graddot and slab.b.blobcenter
+        d_raw = dev(torch, raws)
+        for _ in range(2):
+            ctx.frame_buffers(p, d_raw, B, slab.b)
+        ctx.sync()
+        model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+        cnt = slab.counters()
+        for k in range(B):
+            s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+            m, widx, wcnt = port.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                       cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+            assert np.array_equal(slab.flat(k), s["flat"]) and np.array_equal(slab.sat(k), port.sat_i32(s["graddot"])[0]) and np.array_equal(cnt[k], wcnt)
+            n = int(wcnt[0])
+            assert np.array_equal(slab.idx(k)[:n], widx) and slab.matches(k)[:22 * n].tobytes() == m.tobytes()
+        gd = ctx.d2h(slab.b.graddot, (B, cfg.fh, cfg.fw), np.float32)
+        assert np.array_equal(gd[0], s["graddot"]) if B == 1 else gd.shape[0] == B
+        flat_t, sat_t, m_t, idx_t, cnt_t = slab.torch_views()  # zero-copy torch views of the same memory
+        assert np.array_equal(cnt_t.cpu().numpy(), cnt) and np.array_equal(sat_t[B - 1].cpu().numpy(), slab.sat(B - 1))
+        del flat_t, sat_t, m_t, idx_t, cnt_t
+        slab.destroy()
+        with pytest.raises(capi.VpError):  # a view the variant cannot produce is refused before anything is allocated
+            ctx.frame_slab(capi.frame_params(cfg, sat_variant=capi.SAT_LOCAL), B, views=capi.VIEW_GRADDOT)
+        # bench-sized request: 2 x 1.6 GB, candidates probed (how many depends on the device's state; the kept blocks are the fastest seen)
+        big = ctx.frame_slab(capi.frame_params(CFG), B_BENCH)
+        ps, pf = big.placement["sat"], big.placement["flat"]
+        assert ps["selected"] and ps["candidates"] >= 2 and ps["write_gbs"] == ps["best_gbs"] >= pf["write_gbs"] >= ps["worst_gbs"] > 1000, big.placement
+        big.destroy()
+        ctx.tune("placement_candidates", 0)
+        plain = ctx.frame_slab(capi.frame_params(CFG), 64)
+        assert plain.placement["sat"]["selected"] is False
+        plain.destroy()
+        # the building block alone
+        lib = capi.lib()
+        ctx.tune("placement_candidates", 6)
+        ptrs, info = (C.c_void_p * 2)(), (capi.VpPlacement * 2)()
+        assert lib.vp_malloc_device_placed(ctx.h, C.c_size_t(1 << 30), 2, ptrs, info) == 0, lib.vp_last_error()
+        assert ptrs[0] and ptrs[1] and ptrs[0] != ptrs[1] and 2 <= info[0].candidates <= 6 and info[0].write_gbs >= info[1].write_gbs > 0
+        for q in ptrs:
+            ctx.free(q)
+    finally:
+        ctx.close()

@@ -38,6 +38,17 @@ class VpFrameBuffers(C.Structure):
                 ("planes", C.c_void_p), ("graddot", C.c_void_p), ("blobcenter", C.c_void_p)]
 
 
+class VpPlacement(C.Structure):
+    _fields_ = [("write_gbs", C.c_float), ("best_gbs", C.c_float), ("worst_gbs", C.c_float), ("candidates", C.c_int32), ("selected", C.c_int32)]
+
+    def as_dict(self):
+        return {"write_gbs": round(self.write_gbs, 1), "best_gbs": round(self.best_gbs, 1), "worst_gbs": round(self.worst_gbs, 1), "candidates": int(self.candidates),
+                "selected": bool(self.selected)}
+
+
+VIEW_PLANES, VIEW_GRADDOT, VIEW_BLOBCENTER = 1, 2, 4
+
+
 class VpStageTime(C.Structure):
     _fields_ = [("stage", C.c_char_p), ("ms", C.c_float)]
 
@@ -259,9 +270,70 @@ class Context:
     def circularize(self, graddot, w, h, batch, min_r, max_r, out, stream=0):
         self._ck(self.l.vp_circularize(self.h, stream, _ptr(graddot), int(w), int(h), int(batch), int(min_r), int(max_r), _ptr(out)))
 
+    def frame_slab(self, params: VpFrameParams, batch, views=0) -> "FrameSlab":
+        return FrameSlab(self, params, batch, views)
+
+    def frame_buffers(self, params: VpFrameParams, raw, batch, buffers: VpFrameBuffers, stream=0):
+        """vp_frame on a VpFrameBuffers (e.g. FrameSlab.b)."""
+        self._ck(self.l.vp_frame(self.h, stream, C.byref(params), _ptr(raw), int(batch), C.byref(buffers)))
+
     def frame(self, params: VpFrameParams, raw, batch, flat, sat, matches, counter, idx=None, planes=None, graddot=None, blobcenter=None, stream=0):
         b = VpFrameBuffers(_ptr(flat), _ptr(sat), _ptr(matches), _ptr(idx), _ptr(counter), _ptr(planes), _ptr(graddot), _ptr(blobcenter))
         self._ck(self.l.vp_frame(self.h, stream, C.byref(params), _ptr(raw), int(batch), C.byref(b)))
+
+
+def as_torch(ptr, shape, typestr):
+    """Zero-copy torch view of library-owned device memory (typestr as in numpy: "|u1", "<i4", "<f4"); the owner must outlive the view."""
+    import torch
+
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(v, device="cuda")
+
+
+class FrameSlab:
+    """vp_frame_buffers_create: every buffer vp_frame writes for `batch` frames, allocated once by the library (the table and flat from
+    placement-checked blocks).  `.b` is the VpFrameBuffers to hand to Context.frame_buffers(); the accessors copy single frames to the host."""
+
+    def __init__(self, ctx, params, batch, views=0):
+        self.ctx, self.batch = ctx, int(batch)
+        self.fw, self.fh, self.mm = int(params.fw), int(params.fh), int(params.max_matches)
+        self.b = VpFrameBuffers()
+        self.h = C.c_void_p()
+        ctx._ck(ctx.l.vp_frame_buffers_create(ctx.h, C.byref(params), int(batch), int(views), C.byref(self.b), C.byref(self.h)))
+        sat, flat = VpPlacement(), VpPlacement()
+        ctx._ck(ctx.l.vp_frame_buffers_placement(self.h, C.byref(sat), C.byref(flat)))
+        self.placement = {"sat": sat.as_dict(), "flat": flat.as_dict()}
+
+    def torch_views(self):
+        """(flat, sat or None, matches, idx, counter) as torch tensors over the slab's memory."""
+        B, mm = self.batch, self.mm
+        return (as_torch(self.b.flat, (B, self.fh, self.fw, 4), "|u1"), as_torch(self.b.sat, (B, self.fh, self.fw), "<i4") if self.b.sat else None,
+                as_torch(self.b.matches, (B, 22 * mm), "|u1"), as_torch(self.b.idx, (B, mm), "<i4"), as_torch(self.b.counter, (B, 3), "<i4"))
+
+    def flat(self, k):
+        n = self.fw * self.fh * 4
+        return self.ctx.d2h(self.b.flat + k * n, (self.fh, self.fw, 4), np.uint8)
+
+    def sat(self, k):
+        n = self.fw * self.fh * 4
+        return self.ctx.d2h(self.b.sat + k * n, (self.fh, self.fw), np.int32)
+
+    def counters(self):
+        return self.ctx.d2h(self.b.counter, (self.batch, 3), np.int32)
+
+    def idx(self, k):
+        return self.ctx.d2h(self.b.idx + k * 4 * self.mm, (self.mm,), np.uint32)
+
+    def matches(self, k):
+        return self.ctx.d2h(self.b.matches + k * 22 * self.mm, (22 * self.mm,), np.uint8)
+
+    def destroy(self):
+        if self.h:
+            self.ctx._ck(self.ctx.l.vp_frame_buffers_destroy(self.ctx.h, self.h))
+            self.h = None
 
 
 def sorted_blobs(matches_bytes, idx, counter, max_matches):

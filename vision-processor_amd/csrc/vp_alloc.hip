@@ -1,0 +1,192 @@
+// Device memory with a checked placement (include/vp_hip.h: vp_probe_stream, vp_malloc_device_placed, vp_frame_buffers_*).
+//
+// Why this exists: the gradientDot + SAT pass is HBM-bound and its duration moves by up to 15 % with the physical pages its input and output
+// happen to get from hipMalloc (profiles/r02_bench_spread.json).  The reference allocates every image once and keeps it in a
+// pool for the life of the process (OpenCL::acquire, opencl.cpp:108-122; CLArray, opencl.cpp:137-159), so where an allocation lands is decided
+// once -- and can be decided deliberately.
+#include "vp_common.h"
+
+#include <algorithm>
+#include <cstring>
+
+// ---- stream probes: what a buffer's placement gives a pure 16-byte-per-lane read or write stream --------------------------------------
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_probe_read(const v4u* __restrict__ in, size_t n16, unsigned* __restrict__ sink) {
+	v4u acc = {0, 0, 0, 0};
+	for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+		const v4u v = __builtin_nontemporal_load(in + i);
+		acc ^= v;
+	}
+	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = acc.x; // practically never: keeps the loads alive
+}
+__global__ __launch_bounds__(256) void k_probe_write(v4u* __restrict__ out, size_t n16) {
+	for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v4u{0u, 0u, 0u, 0u}, out + i);
+}
+
+// mean microseconds of `reps` launches of a pure read (write = 0) or zero-fill (write = 1: the buffer's contents are lost) stream over the buffer
+int vp_probe_stream_impl(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us) {
+	VP_REQUIRE(ptr && bytes >= 4096 && reps >= 1 && us && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "vp_probe_stream: bad arguments");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	hipStream_t s = ctx->streams[stream];
+	void* sink = nullptr;
+	VP_TRY(vp_workspace(ctx, stream, 0, 256, &sink));
+	hipEvent_t e0, e1;
+	VP_CHECK_HIP(hipEventCreate(&e0));
+	VP_CHECK_HIP(hipEventCreate(&e1));
+	const unsigned grid = (unsigned)ctx->cu_count * 16;
+	const size_t n16 = bytes / 16;
+	for(int i = -1; i < reps; i++) {
+		if(i == 0) (void)hipEventRecord(e0, s);
+		if(write) k_probe_write<<<grid, 256, 0, s>>>(static_cast<v4u*>(ptr), n16);
+		else k_probe_read<<<grid, 256, 0, s>>>(static_cast<const v4u*>(ptr), n16, static_cast<unsigned*>(sink));
+	}
+	(void)hipEventRecord(e1, s);
+	hipError_t e = hipEventSynchronize(e1);
+	float ms = 0.f;
+	if(e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	VP_CHECK_HIP(e);
+	*us = ms * 1e3f / (float)reps;
+	return vp_launch_ok("stream probe");
+}
+
+extern "C" int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	return vp_probe_stream_impl(ctx, stream, ptr, bytes, write, reps, us);
+}
+
+// ---- placement-checked allocation -----------------------------------------------------------------------------------------------------
+// What was measured (tools/placement_scan.py, profiles/r03_placement.json): the zero-fill stream of a 1.6 GB hipMalloc buffer runs at either
+// 4.95-5.4 TB/s or 3.8-4.4 TB/s; the figure belongs to the allocation (identical on every later sweep, identical for a buffer re-allocated at
+// once), not to its virtual address (the same address range is fast in one allocation and slow in the next), clusters in allocation order (22
+// consecutive allocations = 33 GB all fast, ~30 % of 100 overall) and leaves read streams untouched (6.7-6.9 TB/s everywhere).  The SAT pass writes
+// its table once per launch: 608 us into a fast allocation, 650-705 us into a slow one.  So: allocate candidates WITHOUT freeing (a freed block is
+// handed out again by the next hipMalloc), probe each, keep the fastest, free the rest.
+int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info) {
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	for(int i = 0; i < count; i++) dptrs[i] = nullptr;
+	const int budget = ctx->tune.placement_candidates;
+	// below a few Infinity Caches (256 MiB) a write stream never reaches HBM at its own pace: nothing to measure, nothing to gain
+	const bool select = budget > count && bytes >= (size_t(768) << 20);
+	struct Cand {
+		void* p;
+		float gbs;
+	};
+	std::vector<Cand> cands;
+	auto release_all = [&] {
+		for(const Cand& c : cands) (void)hipFree(c.p);
+		cands.clear();
+	};
+	size_t free_b = 0, total_b = 0;
+	VP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+	const size_t spend = free_b / 2; // never hold more than half of what is free while searching
+	int good = 0;
+	while((int)cands.size() < (select ? budget : count)) {
+		if(select && (int)cands.size() >= count && (cands.size() + 1) * bytes > spend) break;
+		void* p = nullptr;
+		if(hipMalloc(&p, bytes) != hipSuccess) {
+			(void)hipGetLastError();
+			if((int)cands.size() >= count) break; // enough to hand out: stop searching
+			release_all();
+			vp_set_error("hipMalloc(%zu) failed (buffer %d of %d)", bytes, (int)cands.size() + 1, count);
+			return VP_ERR_NOMEM;
+		}
+		float us = 0.f;
+		if(select) {
+			const int rc = vp_probe_stream_impl(ctx, 0, p, bytes & ~size_t(15), 1, 3, &us);
+			if(rc != VP_OK) {
+				(void)hipFree(p);
+				release_all();
+				return rc;
+			}
+		}
+		const float gbs = us > 0.f ? (float)((double)bytes / us * 1e-3) : 0.f;
+		cands.push_back({p, gbs});
+		if(select && gbs >= VP_PLACEMENT_FAST_GBS && ++good >= count) break;
+	}
+	std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.gbs > b.gbs; });
+	for(int i = 0; i < count; i++) {
+		dptrs[i] = cands[i].p;
+		if(info) info[i] = VpPlacement{cands[i].gbs, cands.front().gbs, cands.back().gbs, (int32_t)cands.size(), select ? 1 : 0};
+	}
+	for(size_t i = count; i < cands.size(); i++) (void)hipFree(cands[i].p);
+	return VP_OK;
+}
+
+extern "C" int vp_malloc_device_placed(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info) {
+	VP_REQUIRE(ctx && dptrs && bytes > 0 && count >= 1 && count <= 64, "vp_malloc_device_placed: bad arguments");
+	return vp_malloc_device_placed_impl(ctx, bytes, count, dptrs, info);
+}
+
+// ---- frame buffers: everything vp_frame writes for `batch` frames of one geometry, allocated once (the reference's image pool, opencl.cpp:108-122) ----
+struct VpFrameSlab {
+	std::vector<void*> blocks;
+	VpFrameBuffers buffers;
+	VpPlacement placement[2]; // [0] the table, [1] flat
+};
+
+extern "C" int vp_frame_buffers_create(VpContext* ctx, const VpFrameParams* p, int batch, int views, VpFrameBuffers* out, VpFrameSlab** slab_out) {
+	VP_REQUIRE(ctx && p && out && slab_out && batch > 0 && batch <= 65535 && p->fw > 0 && p->fh > 0 && p->qw > 0 && p->qh > 0 && p->max_matches > 0, "vp_frame_buffers_create: bad arguments");
+	VP_REQUIRE((views & ~(VP_VIEW_PLANES | VP_VIEW_GRADDOT | VP_VIEW_BLOBCENTER)) == 0, "vp_frame_buffers_create: unknown view bits %#x", views);
+	const bool local = p->sat_variant == VP_SAT_LOCAL;
+	VP_REQUIRE(!local || !(views & (VP_VIEW_GRADDOT | VP_VIEW_BLOBCENTER)), "vp_frame_buffers_create: VP_SAT_LOCAL has no gradDot / blobCenter view");
+	VpFrameSlab* slab = new VpFrameSlab();
+	memset(&slab->buffers, 0, sizeof(slab->buffers));
+	memset(slab->placement, 0, sizeof(slab->placement));
+	const size_t npx = (size_t)p->fw * p->fh * batch;
+	int rc = VP_OK;
+	auto plain = [&](size_t bytes, void** dst) {
+		if(rc != VP_OK) return;
+		rc = vp_malloc_device(ctx, bytes, dst);
+		if(rc == VP_OK) slab->blocks.push_back(*dst);
+	};
+	// the two image-sized buffers the path WRITES every frame are the ones whose placement matters: the fastest-writing candidate becomes the
+	// table (8 B/px pass, HBM-bound), the next one flat (written by the VALU-bound resampling kernel)
+	void* big[2] = {nullptr, nullptr};
+	const int n_big = local ? 1 : 2;
+	rc = vp_malloc_device_placed_impl(ctx, npx * 4, n_big, big, slab->placement);
+	if(rc == VP_OK) {
+		for(int i = 0; i < n_big; i++) slab->blocks.push_back(big[i]);
+		if(local) {
+			slab->buffers.flat = static_cast<uint8_t*>(big[0]);
+			slab->placement[1] = slab->placement[0];
+			memset(&slab->placement[0], 0, sizeof(VpPlacement));
+		} else {
+			slab->buffers.sat = static_cast<int32_t*>(big[0]);
+			slab->buffers.flat = static_cast<uint8_t*>(big[1]);
+		}
+	}
+	plain(sizeof(VpMatch) * (size_t)p->max_matches * batch, reinterpret_cast<void**>(&slab->buffers.matches));
+	plain(sizeof(uint32_t) * (size_t)p->max_matches * batch, reinterpret_cast<void**>(&slab->buffers.idx));
+	plain(sizeof(int32_t) * 3 * (size_t)batch, reinterpret_cast<void**>(&slab->buffers.counter));
+	if(views & VP_VIEW_PLANES) plain((size_t)4 * p->qw * p->qh * batch, reinterpret_cast<void**>(&slab->buffers.planes));
+	if(views & VP_VIEW_GRADDOT) plain(npx * 4, reinterpret_cast<void**>(&slab->buffers.graddot));
+	if(views & VP_VIEW_BLOBCENTER) plain(npx * 4, reinterpret_cast<void**>(&slab->buffers.blobcenter));
+	if(rc != VP_OK) {
+		for(void* b : slab->blocks) (void)hipFree(b);
+		delete slab;
+		return rc;
+	}
+	*out = slab->buffers;
+	*slab_out = slab;
+	return VP_OK;
+}
+
+extern "C" int vp_frame_buffers_placement(const VpFrameSlab* slab, VpPlacement* sat, VpPlacement* flat) {
+	VP_REQUIRE(slab, "null slab");
+	if(sat) *sat = slab->placement[0];
+	if(flat) *flat = slab->placement[1];
+	return VP_OK;
+}
+
+extern "C" int vp_frame_buffers_destroy(VpContext* ctx, VpFrameSlab* slab) {
+	VP_REQUIRE(ctx, "null context");
+	if(!slab) return VP_OK;
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	for(int i = 0; i < ctx->n_streams; i++) VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[i]));
+	for(void* b : slab->blocks) (void)hipFree(b);
+	delete slab;
+	return VP_OK;
+}

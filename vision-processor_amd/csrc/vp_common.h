@@ -49,6 +49,7 @@ struct VpTuning {
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
+	int placement_candidates = 48; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives)
 };
 
 struct VpContext {
@@ -112,6 +113,10 @@ static inline int vp_check_ctx(VpContext* ctx, int stream) {
 // Scratch of at least `bytes` on `stream` in `slot`; grows (stream-synchronising, zero-filled) only when too small.
 // *grew (optional) tells the caller that persistent contents were lost.
 int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out, bool* grew = nullptr);
+
+// vp_alloc.hip
+int vp_probe_stream_impl(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us);
+#define VP_PLACEMENT_FAST_GBS 4700.f // zero-fill rate that separates the two populations of 1.6 GB allocations on MI355X (4.95-5.4 vs 3.8-4.4 TB/s)
 
 // RAII bracket for per-stage hipEvent timing (the cl::Event list of opencl.h:84)
 struct VpStageTimer {
