@@ -302,6 +302,15 @@ int vp_frame_buffers_destroy(VpContext* ctx, VpFrameSlab* slab);
 /* raw -> blob list for `batch` frames on one stream, no host synchronisation inside. */
 int vp_frame(VpContext* ctx, int stream, const VpFrameParams* params, const uint8_t* raw, int batch, const VpFrameBuffers* buffers);
 
+/* ---- transport form of a step's blob lists ------------------------------------------------------------------------------------------
+ * vp_frame fills fixed-capacity arrays (max_matches records per frame, main.cpp:257: 52 KB per frame at maxBlobs 2000) of which a frame uses a few
+ * per cent; what the host loop reads back is counter[3] and min(counter[0], maxBlobs) records (main.cpp:299-301).  vp_records_compact copies exactly
+ * that into one slot per frame: [counter 3 x int32 | n int32 | cap x VpMatch | pad | cap x uint32 pixel index], slot size padded to 16 bytes, with
+ * n = min(counter[0], max_matches, cap) records and indices present (idx may be NULL).  vp_record_layout_compact returns the size of `batch` slots
+ * (a multiple of 256) and the slot size / offsets.  This is what vp_feeds reads back and what its multi-GPU gather carries (include/vp_multi.h). */
+size_t vp_record_layout_compact(int batch, int cap, size_t* slot_bytes, size_t* off_matches, size_t* off_idx);
+int vp_records_compact(VpContext* ctx, int stream, const int32_t* counter, const VpMatch* matches, const uint32_t* idx, int batch, int max_matches, int cap, uint8_t* out);
+
 /* ---- synthetic input (libvp_host.so; host-side, no GPU) --------------------------------------------------------------
  * Deterministic test/benchmark frames; not part of the reference. */
 int vp_synth_frame(const VpCameraModel* model, int layout, int qw, int qh, float plane_height, float field_len, float field_wid,

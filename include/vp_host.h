@@ -141,6 +141,13 @@ int vph_gc_close(VphDetector* d);
 int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, const int32_t* counters, int max_matches, uint32_t frame_id, double start_time,
 		double img_timestamp, double t_sent, int threads, uint8_t* packets, int packet_cap, int32_t* lengths);
 
+/* The same step with the transport forms on both sides: feed i reads slot i of a compact record block (vp_records_compact, vp_hip.h: [counter 3 x int32 |
+ * n | records], slot_bytes apart) and writes slot i of a packet block (vp_packet_layout, vp_multi.h: [int32 length | payload], packet_slot_bytes
+ * apart; length = -needed when the slot is too small).  A record slot that holds fewer records than min(max_matches, counter[0]) would drop blobs:
+ * VP_ERR_INVALID, nothing is run. */
+int vph_detect_batch_slots(VphDetector* const* ds, int n, const uint8_t* slots, size_t slot_bytes, int max_matches, uint32_t frame_id, double start_time, double img_timestamp,
+		double t_sent, int threads, uint8_t* packet_block, int packet_slot_bytes);
+
 /* building blocks, exported for the unit tests */
 float vph_atan2_fast(float y, float x);                                                              /* hypothesis.cpp:35-58 */
 int vph_kmeans(const int32_t contrast[3], const int32_t* values, int n, int32_t c1[3], int32_t c2[3]); /* kmeans.cpp:19-90 */

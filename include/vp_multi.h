@@ -8,8 +8,13 @@
  * information is the blob records each device's vp_frame produced; every device receives every device's records
  * (ncclCommInitAll + ncclAllGather on uint8, equal counts, latency-bound).
  *
- * Record block of one device and step (what vp_record_layout describes; vp_frame writes straight into it, nothing is packed):
- *     [counter: batch x 3 int32, padded to 256 B][matches: batch x max_matches x 22 B, padded][idx: batch x max_matches x uint32, padded]
+ * What a device contributes per step -- three forms, all fixed-size so that ONE all-gather with equal counts carries them:
+ *   full records    vp_record_layout: [counter: batch x 3 int32, padded to 256 B][matches: batch x max_matches x 22 B, padded][idx: batch x
+ *                   max_matches x uint32, padded]; vp_frame writes straight into it, nothing is packed (6.7 MB at 128 feeds x 2000 blobs);
+ *   compact records vp_record_layout_compact / vp_records_compact (vp_hip.h): per feed counter[3], n and the n records a host would read
+ *                   (main.cpp:299-301), `cap` records per slot (0.66 MB at 128 feeds, cap 192);
+ *   packets         vp_packet_layout: per feed one slot [int32 length | SSL_WrapperPacket bytes]: what the reference's cameras actually exchange
+ *                   (udpsocket.cpp:94-100), produced by the CPU stage (vph_detect_batch) of each device's feeds (0.5 MB at 128 feeds x 4 KB).
  *
  * Errors: VpStatus + vp_last_error() as in vp_hip.h.  No CPU fallback: without RCCL and a HIP device creation fails.
  */
@@ -26,6 +31,10 @@ typedef struct VpGather VpGather;
 
 /* Byte offsets of the three arrays inside one device's record block; returns the block size (a multiple of 256). */
 size_t vp_record_layout(int batch, int max_matches, size_t* off_counter, size_t* off_matches, size_t* off_idx);
+
+/* Packet block: `batch` slots of slot_bytes (a multiple of 4, > 4), slot i = [int32 length | payload of at most slot_bytes - 4 bytes]; length <= 0 = no
+ * packet.  Returns the block size (a multiple of 256), 0 for bad arguments. */
+size_t vp_packet_layout(int batch, int slot_bytes);
 
 /* One communicator per device (ncclCommInitAll over devices[0..n)), one gather stream per device, n_slots (1..4) send / receive
  * buffer pairs per device so that the gather of step k runs beside the kernels of step k + 1. */

@@ -278,6 +278,11 @@ def test_native_multi_gpu_feeds_gather_through_rccl(port):
     assert out.returncode == 0, out.stdout + out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["gpus"] == n and r["gather_verified"] is True and "ncclAllGather" in r["gather"] and r["sat_variant"] == "tiled"
+    assert r["block"] == "compact records" and r["record_bytes_per_gpu"] * 10 <= r["full_record_bytes_per_gpu"]  # the gather is sized to its content
+    full = subprocess.run([exe, "--gpus", str(n), str(feeds), "2", "1", "--verify", "--full-records"], capture_output=True, text=True, timeout=600, env=envv)
+    assert full.returncode == 0, full.stdout + full.stderr
+    rf = json.loads(full.stdout.strip().splitlines()[-1])
+    assert rf["block"] == "full records" and rf["gather_verified"] is True and rf["counters"] == r["counters"]
     out2 = subprocess.run([exe, "--gpus", str(n), str(feeds), "3", "1", "--verify", "--local"], capture_output=True, text=True, timeout=600, env=envv)
     assert out2.returncode == 0, out2.stdout + out2.stderr
     r2 = json.loads(out2.stdout.strip().splitlines()[-1])
@@ -290,44 +295,67 @@ def test_native_multi_gpu_feeds_gather_through_rccl(port):
             assert r["counters"][g][i] == [int(v) for v in want["cnt"]], (g, i)
 
 
-def test_gather_abi_in_process(env):
-    """include/vp_multi.h through ctypes: N = visible devices, two slots, blocks filled by device copies on the contexts' streams; after
-    vp_gather_start / vp_gather_wait every device's receive area holds all blocks in rank order."""
-    capi, torch = env
+GATHER_ABI_CHILD = r"""
+import ctypes as C, os, sys
+import numpy as np
+root = sys.argv[1]
+hip = C.CDLL(os.path.join(root, "vision-processor_amd", "libvp_hip.so"), mode=C.RTLD_GLOBAL)
+multi = C.CDLL(os.path.join(root, "vision-processor_amd", "libvp_multi.so"))
+hip.vp_last_error.restype = C.c_char_p
+multi.vp_gather_send.restype = C.c_void_p
+multi.vp_gather_recv.restype = C.c_void_p
+multi.vp_record_layout.restype = C.c_size_t
+multi.vp_packet_layout.restype = C.c_size_t
+hip.vp_record_layout_compact.restype = C.c_size_t
+n = hip.vp_device_count()
+assert n >= 1
+nbytes = multi.vp_record_layout(2, 64, None, None, None)
+assert nbytes > 0 and nbytes % 256 == 0
+assert multi.vp_packet_layout(3, 4096) == 12288 and multi.vp_packet_layout(3, 4) == 0 and multi.vp_packet_layout(0, 4096) == 0
+slot = C.c_size_t()
+assert hip.vp_record_layout_compact(128, 192, C.byref(slot), None, None) * 10 <= multi.vp_record_layout(128, 2000, None, None, None) and slot.value % 16 == 0
+ctxs = []
+for d in range(n):
+    h = C.c_void_p()
+    assert hip.vp_ctx_create(d, 2, C.byref(h)) == 0, hip.vp_last_error()
+    ctxs.append(h)
+g = C.c_void_p()
+devs = (C.c_int * n)(*range(n))
+assert multi.vp_gather_create(n, devs, C.c_size_t(nbytes), 2, C.byref(g)) == 0, hip.vp_last_error()
+harr = (C.c_void_p * n)(*[c.value for c in ctxs])
+for slot_i in (0, 1, 0):
+    blocks = [np.random.default_rng(17 * slot_i + r).integers(0, 256, nbytes, dtype=np.uint8) for r in range(n)]
+    for r in range(n):
+        assert hip.vp_copy_h2d(ctxs[r], slot_i, C.c_void_p(multi.vp_gather_send(g, r, slot_i)), blocks[r].ctypes.data_as(C.c_void_p), C.c_size_t(nbytes)) == 0
+        assert hip.vp_sync(ctxs[r], slot_i) == 0
+    streams = (C.c_int * n)(*([slot_i] * n))
+    assert multi.vp_gather_start(g, slot_i, harr, streams) == 0, hip.vp_last_error()
+    assert multi.vp_gather_wait(g, slot_i) == 0
+    for r in range(n):
+        got = np.empty((n, nbytes), np.uint8)
+        assert hip.vp_copy_d2h_sync(ctxs[r], slot_i, got.ctypes.data_as(C.c_void_p), C.c_void_p(multi.vp_gather_recv(g, r, slot_i)), C.c_size_t(got.nbytes)) == 0
+        for q in range(n):
+            assert np.array_equal(got[q], blocks[q]), (slot_i, r, q)
+if n >= 2:  # a context on the wrong device is refused
+    swapped = (C.c_void_p * n)(*[c.value for c in reversed(ctxs)])
+    assert multi.vp_gather_start(g, 0, swapped, streams) != 0
+multi.vp_gather_destroy(g)
+for c in ctxs:
+    hip.vp_ctx_destroy(c)
+print("GATHER_ABI_OK", n)
+"""
+
+
+def test_gather_abi_in_a_child_process():
+    """include/vp_multi.h through ctypes, in a child process WITHOUT torch (libvp_multi.so brings the system HIP runtime and RCCL, which must not meet
+    PyTorch's bundled copies in one process): N = visible devices, two slots, blocks filled by device copies on the contexts' streams; after
+    vp_gather_start / vp_gather_wait every device's receive area holds all blocks in rank order; the three block layouts report their sizes."""
     import os
-    n = torch.cuda.device_count()
-    lib = capi.lib()
-    multi = C.CDLL(os.path.join(cases.ROOT, "vision-processor_amd", "libvp_multi.so"))
-    multi.vp_gather_send.restype = C.c_void_p
-    multi.vp_gather_recv.restype = C.c_void_p
-    multi.vp_record_layout.restype = C.c_size_t
-    nbytes = multi.vp_record_layout(2, 64, None, None, None)
-    assert nbytes > 0 and nbytes % 256 == 0
-    ctxs = [capi.Context(d, n_streams=2) for d in range(n)]
-    g = C.c_void_p()
-    devs = (C.c_int * n)(*range(n))
-    assert multi.vp_gather_create(n, devs, C.c_size_t(nbytes), 2, C.byref(g)) == 0, lib.vp_last_error()
-    try:
-        harr = (C.c_void_p * n)(*[c.h for c in ctxs])
-        for slot in (0, 1, 0):
-            blocks = [np.random.default_rng(17 * slot + r).integers(0, 256, nbytes, dtype=np.uint8) for r in range(n)]
-            for r in range(n):
-                ctxs[r].h2d(multi.vp_gather_send(g, r, slot), blocks[r], stream=slot)
-            streams = (C.c_int * n)(*([slot] * n))
-            assert multi.vp_gather_start(g, slot, harr, streams) == 0, lib.vp_last_error()
-            assert multi.vp_gather_wait(g, slot) == 0
-            for r in range(n):
-                got = ctxs[r].d2h(multi.vp_gather_recv(g, r, slot), (n, nbytes), np.uint8, stream=slot)
-                for q in range(n):
-                    assert np.array_equal(got[q], blocks[q]), (slot, r, q)
-        # a context on the wrong device is refused
-        if n >= 2:
-            swapped = (C.c_void_p * n)(*[c.h for c in reversed(ctxs)])
-            assert multi.vp_gather_start(g, 0, swapped, streams) != 0
-    finally:
-        multi.vp_gather_destroy(g)
-        for c in ctxs:
-            c.close()
+    import subprocess
+    import sys
+    envv = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([sys.executable, "-c", GATHER_ABI_CHILD, cases.ROOT], capture_output=True, text=True, timeout=600, env=envv)
+    assert out.returncode == 0 and "GATHER_ABI_OK" in out.stdout, out.stdout + out.stderr
 
 
 # ---- VP_SAT_LOCAL: no global table ---------------------------------------------------------------------------------------------------

@@ -262,3 +262,72 @@ def test_frame_buffers_allocator(env, port):
             ctx.free(q)
     finally:
         ctx.close()
+
+
+def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
+    """BASELINE configs[3] as written, in C++ on the C ABIs alone: `vp_feeds --gpus N --detect` (N = every visible device) -- one driver thread per
+    device, vp_frame -> compact record slots -> CPU hypothesis stage -> SSL_WrapperPacket slots -> ONE grouped ncclAllGather per step through real
+    RCCL.  The program checks that every device received every owner's block byte for byte (--verify); here the packets the LAST device received
+    in the last step are parsed with google.protobuf and held to the CPU checkers for the same feed seeds: the hot-path oracle's blob list pushed
+    through oracle/detect_oracle.py for the same number of steps (colour model and tracker carried along), binary32 fields bit for bit.  Replaces
+    main.cpp:319-370 + udpsocket.cpp:94-100; the gather block is 13 x smaller than the raw record arrays."""
+    import json
+    import torch
+    import detect_oracle as D
+    import test_detection_stage as S
+    import test_wire_format as W
+    n = torch.cuda.device_count()
+    exe = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_feeds")
+    envv = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    feeds, steps, warmup = 3, 3, 1
+    dump = str(tmp_path / "gathered.bin")
+    out = subprocess.run([exe, "--gpus", str(n), str(feeds), str(steps), str(warmup), "--detect", "--threads", "8", "--verify", "--dump", dump], capture_output=True, text=True, timeout=900, env=envv)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["gpus"] == n and r["gather_verified"] is True and r["block"] == "SSL_WrapperPacket slots" and "ncclAllGather" in r["gather"]
+    assert r["record_bytes_per_gpu"] * 10 <= r["full_record_bytes_per_gpu"]
+    assert r["detect"]["robots_per_frame"] == 16.0 and 8.0 <= r["detect"]["balls_per_frame"] <= 9.0 and 500 < r["detect"]["packet_bytes_per_frame"] < 1500
+    slot = r["detect"]["packet_slot_bytes"]
+    blob = open(dump, "rb").read()
+    block = len(blob) // n
+    assert len(blob) == n * block and block >= feeds * slot
+    cfg, mm = CFG, CFG.max_matches
+    big = O.Port(threads=min(16, os.cpu_count() or 1))
+    model_o = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    mdl = cfg.model()
+    calib = (mdl.f, mdl.p[0], mdl.p[1], mdl.d, -1.0, 0.0, 0.0, 0.0, -mdl.c[0], mdl.c[1], mdl.c[2])
+    F = np.float32
+    fs, ox, oy = F(cfg.field_scale), F(cfg.off_x), F(cfg.off_y)
+    total = warmup + steps
+    for g in range(n):
+        for i in range(feeds):
+            off = g * block + i * slot
+            length = int(np.frombuffer(blob[off:off + 4], np.int32)[0])
+            assert 0 < length <= slot - 4, (g, i, length)
+            pkt = W.Wrapper()
+            pkt.ParseFromString(blob[off + 4:off + 4 + length])
+            assert pkt.IsInitialized() and pkt.source == 3
+            d = pkt.detection
+            assert d.camera_id == g * feeds + i and d.frame_number == total
+            if g >= 2 and i > 0:
+                continue  # the oracle comparison covers every feed of two devices and one feed of the others
+            m, _, cnt = big.frame(cfg.synth(cases.vp.feeds.feed_seed(g, i)), cfg.layout, cfg.qw, cfg.qh, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y,
+                                  cfg.sampler_mode, cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+            matches = [dict(pos=(F(F(a["x"]) * fs + ox), F(F(a["y"]) * fs + oy)), color=tuple(int(v) for v in a["color"]), center=tuple(int(v) for v in a["center"]), circ=F(a["circ"]),
+                            score=F(a["score"])) for a in m]  # Perspective::flat2field (Perspective.cpp:127-129)
+            res = D.Res(D.Camera(calib, (cfg.qw, cfg.qh), (cfg.qw, cfg.qh)), field_length=9000, field_width=6000, boundary_width=300)
+            res.cam_id = g * feeds + i
+            for k in range(1, total + 1):
+                t = k / 70.0
+                want = D.detect_frame(res, matches, k, t, t)
+                D.detection_tracking(res, want)
+            got = dict(frame_number=d.frame_number, camera_id=d.camera_id, t_capture=d.t_capture, t_capture_camera=d.t_capture_camera if d.HasField("t_capture_camera") else None,
+                       t_offsets=np.asarray(d.t_offsets, np.float32),
+                       balls=[dict(confidence=b.confidence, x=b.x, y=b.y, pixel_x=b.pixel_x, pixel_y=b.pixel_y) for b in d.balls],
+                       robots_yellow=[dict(confidence=b.confidence, robot_id=b.robot_id, x=b.x, y=b.y, orientation=b.orientation, pixel_x=b.pixel_x, pixel_y=b.pixel_y, height=b.height)
+                                      for b in d.robots_yellow],
+                       robots_blue=[dict(confidence=b.confidence, robot_id=b.robot_id, x=b.x, y=b.y, orientation=b.orientation, pixel_x=b.pixel_x, pixel_y=b.pixel_y, height=b.height)
+                                    for b in d.robots_blue])
+            S.assert_frames_equal(got, want)
+            assert d.t_sent == total / 70.0 + 0.002
+            assert len(d.robots_yellow) + len(d.robots_blue) == 16

@@ -38,6 +38,11 @@ extern "C" size_t vp_record_layout(int batch, int max_matches, size_t* off_count
 	return c + m + i;
 }
 
+extern "C" size_t vp_packet_layout(int batch, int slot_bytes) {
+	if(batch <= 0 || slot_bytes <= 4 || (slot_bytes & 3)) return 0;
+	return pad256((size_t)batch * slot_bytes);
+}
+
 extern "C" void vp_gather_destroy(VpGather* g) {
 	if(!g) return;
 	for(int r = 0; r < g->n; r++) {

@@ -282,27 +282,25 @@ int vph_decode(VphDetector* d, const uint8_t* buf, int len, int* source) {
 	return has ? 1 : 0;
 }
 
-int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, const int32_t* counters, int max_matches, uint32_t frame_id, double start_time,
-		double img_timestamp, double t_sent, int threads, uint8_t* packets, int packet_cap, int32_t* lengths) {
-	if(n < 0 || max_matches < 0 || packet_cap < 0 || (n && (!ds || !cl_matches || !counters || !packets || !lengths))) return VP_ERR_INVALID;
+} // extern "C"
+
+// One step of n feeds on host threads.  in(i, &amount) yields feed i's records and how many the host loop reads (main.cpp:301); out(i, bytes) stores its packet.
+template<typename In, typename Out>
+static int detectBatch(VphDetector* const* ds, int n, uint32_t frame_id, double start_time, double img_timestamp, double t_sent, int threads, In in, Out out) {
 	for(int i = 0; i < n; i++)
 		if(!ds[i] || !ds[i]->r.perspective->geometryVersion) return VP_ERR_INVALID;
 	std::atomic<int> next{0};
 	auto work = [&]() {
 		for(int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
 			VphDetector& d = *ds[i];
-			const int amount = std::max(0, std::min(max_matches, counters[3 * i])); // main.cpp:301
-			std::vector<vp::Match> ms = matchesFromCl(*d.r.perspective, cl_matches + (size_t)i * max_matches, amount);
+			int amount = 0;
+			const VpMatch* recs = in(i, &amount);
+			std::vector<vp::Match> ms = matchesFromCl(*d.r.perspective, recs, amount);
 			d.frame = vp::detectFrame(d.r, ms, frame_id, start_time, img_timestamp);
 			d.frame.t_sent = t_sent;
 			const std::vector<uint8_t> bytes = vp::encodeWrapperPacket(d.frame);
 			vp::detectionTracking(d.r, d.frame); // the feed's own packet comes back through the multicast group (udpsocket.cpp:146-154)
-			if((int)bytes.size() > packet_cap) {
-				lengths[i] = -(int32_t)bytes.size();
-				continue;
-			}
-			std::memcpy(packets + (size_t)i * packet_cap, bytes.data(), bytes.size());
-			lengths[i] = (int32_t)bytes.size();
+			out(i, bytes);
 		}
 	};
 	const int nt = std::max(1, std::min(threads, n));
@@ -311,6 +309,50 @@ int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, c
 	work();
 	for(std::thread& t : pool) t.join();
 	return VP_OK;
+}
+
+extern "C" {
+
+int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, const int32_t* counters, int max_matches, uint32_t frame_id, double start_time,
+		double img_timestamp, double t_sent, int threads, uint8_t* packets, int packet_cap, int32_t* lengths) {
+	if(n < 0 || max_matches < 0 || packet_cap < 0 || (n && (!ds || !cl_matches || !counters || !packets || !lengths))) return VP_ERR_INVALID;
+	return detectBatch(ds, n, frame_id, start_time, img_timestamp, t_sent, threads,
+			[&](int i, int* amount) {
+				*amount = std::max(0, std::min(max_matches, counters[3 * i])); // main.cpp:301
+				return cl_matches + (size_t)i * max_matches;
+			},
+			[&](int i, const std::vector<uint8_t>& bytes) {
+				if((int)bytes.size() > packet_cap) {
+					lengths[i] = -(int32_t)bytes.size();
+					return;
+				}
+				std::memcpy(packets + (size_t)i * packet_cap, bytes.data(), bytes.size());
+				lengths[i] = (int32_t)bytes.size();
+			});
+}
+
+int vph_detect_batch_slots(VphDetector* const* ds, int n, const uint8_t* slots, size_t slot_bytes, int max_matches, uint32_t frame_id, double start_time, double img_timestamp,
+		double t_sent, int threads, uint8_t* packet_block, int packet_slot_bytes) {
+	if(n < 0 || max_matches < 0 || packet_slot_bytes <= 4 || slot_bytes < 16 || (n && (!ds || !slots || !packet_block))) return VP_ERR_INVALID;
+	for(int i = 0; i < n; i++) { // a slot too small for its frame would silently drop blobs: refuse the step
+		int32_t head[4];
+		std::memcpy(head, slots + (size_t)i * slot_bytes, sizeof(head));
+		if(head[3] < std::max(0, std::min(max_matches, head[0])) || 16 + sizeof(VpMatch) * (size_t)std::max(0, head[3]) > slot_bytes) return VP_ERR_INVALID;
+	}
+	return detectBatch(ds, n, frame_id, start_time, img_timestamp, t_sent, threads,
+			[&](int i, int* amount) {
+				const uint8_t* slot = slots + (size_t)i * slot_bytes;
+				int32_t head[4];
+				std::memcpy(head, slot, sizeof(head));
+				*amount = std::max(0, std::min(max_matches, head[0])); // main.cpp:301
+				return reinterpret_cast<const VpMatch*>(slot + 16);
+			},
+			[&](int i, const std::vector<uint8_t>& bytes) {
+				uint8_t* dst = packet_block + (size_t)i * packet_slot_bytes;
+				const int32_t len = (int)bytes.size() + 4 > packet_slot_bytes ? -(int32_t)bytes.size() : (int32_t)bytes.size();
+				std::memcpy(dst, &len, 4);
+				if(len > 0) std::memcpy(dst + 4, bytes.data(), bytes.size());
+			});
 }
 
 static int applyGeometry(VphDetector* d, const vp::FieldSize& field, const std::vector<vp::CameraCalibration>& calibs, int img_w, int img_h, float resampling_factor, float* out_f,

@@ -4,8 +4,10 @@
 // This is the loop of src/main.cpp:262-372 for many cameras at once: what a deployment that puts several cameras on one MI355X runs.
 //
 // usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1]
-//        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--verify] [--local]   (feeds_multi.cpp: N devices, RCCL gather of the records;
-//                                                                                             --local = VP_SAT_LOCAL, no global table)
+//        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--detect] [--threads T=16] [--cap C=192] [--full-records] [--local] [--verify] [--dump FILE]
+//            feeds_multi.cpp: N devices, one driver thread each, one RCCL all-gather per step of the encoded SSL_WrapperPackets (--detect: the CPU stage
+//            runs per device on T / N host threads) or of the compact blob records (--cap records per feed; --full-records: the fixed-capacity arrays
+//            as vp_frame writes them); --local = VP_SAT_LOCAL; --verify: every device received every owner's block; --dump: the last device's receive area
 // Scene and geometry: SURVEY.md 8(d) cfg2 (2048x1536 RGGB, nadir camera 5 m over a 9.6 x 7.2 m patch, 16 robots, 8 balls per feed).
 #include <chrono>
 #include <cmath>
@@ -26,7 +28,12 @@
 		} \
 	} while(0)
 
-int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify, int local); // feeds_multi.cpp
+struct MultiOptions { // feeds_multi.cpp
+	int gpus = 1, feeds = 128, steps = 20, warmup = 3;
+	int verify = 0, local = 0, detect = 0, threads = 16, cap = 192, full = 0;
+	const char* dump = nullptr;
+};
+int vp_feeds_run_multi(const MultiOptions& o);
 
 // cfg2: kernel scalars assigned directly
 void vp_feeds_cfg2_params(VpFrameParams* out) {
@@ -59,17 +66,33 @@ void vp_feeds_cfg2_params(VpFrameParams* out) {
 
 int main(int argc, char** argv) {
 	if(argc > 2 && strcmp(argv[1], "--gpus") == 0) {
-		int verify = 0, local = 0, pos[3] = {128, 20, 3}, np = 0;
+#ifdef VP_HAVE_MULTI
+		MultiOptions o;
+		o.gpus = atoi(argv[2]);
+		int pos[3] = {128, 20, 3}, np = 0;
 		for(int i = 3; i < argc; i++) {
-			if(strcmp(argv[i], "--verify") == 0) verify = 1;
-			else if(strcmp(argv[i], "--local") == 0) local = 1;
-			else if(np < 3) pos[np++] = atoi(argv[i]);
+			if(strcmp(argv[i], "--verify") == 0) o.verify = 1;
+			else if(strcmp(argv[i], "--local") == 0) o.local = 1;
+			else if(strcmp(argv[i], "--detect") == 0) o.detect = 1;
+			else if(strcmp(argv[i], "--full-records") == 0) o.full = 1;
+			else if(strcmp(argv[i], "--threads") == 0 && i + 1 < argc) o.threads = atoi(argv[++i]);
+			else if(strcmp(argv[i], "--cap") == 0 && i + 1 < argc) o.cap = atoi(argv[++i]);
+			else if(strcmp(argv[i], "--dump") == 0 && i + 1 < argc) o.dump = argv[++i];
+			else if(argv[i][0] != '-' && np < 3) pos[np++] = atoi(argv[i]);
+			else np = 99;
 		}
-		if(pos[0] < 1 || pos[1] < 1 || pos[2] < 0) {
-			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--verify] [--local]\n");
+		o.feeds = pos[0];
+		o.steps = pos[1];
+		o.warmup = pos[2];
+		if(np > 3 || o.feeds < 1 || o.steps < 1 || o.warmup < 0 || o.threads < 1 || o.cap < 1) {
+			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--detect] [--threads T] [--cap C] [--full-records] [--local] [--verify] [--dump FILE]\n");
 			return 2;
 		}
-		return vp_feeds_run_multi(atoi(argv[2]), pos[0], pos[1], pos[2], verify, local);
+		return vp_feeds_run_multi(o);
+#else
+		fprintf(stderr, "[FATAL] vp_feeds was built without libvp_multi.so (no librccl on the build box): --gpus is not available\n");
+		return 1;
+#endif
 	}
 	const int feeds = argc > 1 ? atoi(argv[1]) : 128, steps = argc > 2 ? atoi(argv[2]) : 20, warmup = argc > 3 ? atoi(argv[3]) : 3;
 	const int threads = argc > 4 ? atoi(argv[4]) : 16, detect = argc > 5 ? atoi(argv[5]) : 1;
@@ -84,7 +107,7 @@ int main(int argc, char** argv) {
 
 	VpContext* ctx = nullptr;
 	CK(vp_ctx_create(0, 2, &ctx));
-	const size_t rawBytes = (size_t)4 * qw * qh, npx = (size_t)fw * fh;
+	const size_t rawBytes = (size_t)4 * qw * qh;
 	// synthetic feeds, resident in HBM before the clock starts
 	uint8_t* dRaw = nullptr;
 	CK(vp_malloc_device(ctx, rawBytes * feeds, (void**)&dRaw));
@@ -98,16 +121,12 @@ int main(int argc, char** argv) {
 	}
 	// two sets of per-step buffers: step k runs on stream k & 1 while the host reads step k - 1 back from the other set
 	VpFrameBuffers buf[2];
+	VpFrameSlab* slab[2];
 	void* hMatches[2];
 	void* hCounter[2];
 	const size_t matchBytes = sizeof(VpMatch) * (size_t)maxBlobs * feeds, counterBytes = sizeof(int32_t) * 3 * (size_t)feeds;
 	for(int s = 0; s < 2; s++) {
-		memset(&buf[s], 0, sizeof(buf[s]));
-		CK(vp_malloc_device(ctx, npx * 4 * feeds, (void**)&buf[s].flat));
-		CK(vp_malloc_device(ctx, npx * 4 * feeds, (void**)&buf[s].sat));
-		CK(vp_malloc_device(ctx, matchBytes, (void**)&buf[s].matches));
-		CK(vp_malloc_device(ctx, sizeof(uint32_t) * (size_t)maxBlobs * feeds, (void**)&buf[s].idx));
-		CK(vp_malloc_device(ctx, counterBytes, (void**)&buf[s].counter));
+		CK(vp_frame_buffers_create(ctx, &p, feeds, 0, &buf[s], &slab[s])); // allocated once, the table and flat from placement-checked blocks
 		CK(vp_malloc_host(ctx, matchBytes, &hMatches[s]));
 		CK(vp_malloc_host(ctx, counterBytes, &hCounter[s]));
 	}
@@ -193,11 +212,7 @@ int main(int argc, char** argv) {
 
 	for(VphDetector* d : detectors) vph_detector_destroy(d);
 	for(int s = 0; s < 2; s++) {
-		vp_free_device(ctx, buf[s].flat);
-		vp_free_device(ctx, buf[s].sat);
-		vp_free_device(ctx, buf[s].matches);
-		vp_free_device(ctx, buf[s].idx);
-		vp_free_device(ctx, buf[s].counter);
+		vp_frame_buffers_destroy(ctx, slab[s]);
 		vp_free_host(ctx, hMatches[s]);
 		vp_free_host(ctx, hCounter[s]);
 	}

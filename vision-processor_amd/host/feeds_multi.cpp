@@ -1,17 +1,25 @@
-// vp_feeds --gpus N: the multi-GPU form of the feed pipeline, ONE process on the C ABIs alone (include/vp_hip.h, vp_multi.h).
-// Feeds are sharded over the devices (feed i of device g has the seed feed_seed(g, i) of vision-processor_amd/feeds.py); every
-// device runs vp_frame for its own feeds on its own streams, writing counters / records / indices straight into its record
-// block; after each step ONE grouped RCCL all-gather (vp_gather_start) hands every device every device's block, on the gather
-// streams, while the next step's kernels run.  This is what replaces the reference's per-camera processes exchanging packets
-// over UDP multicast (src/udpsocket.cpp:94-100, 147-163; one loop per camera: src/main.cpp:262-317).
+// vp_feeds --gpus N: the multi-GPU form of the feed pipeline, ONE process on the C ABIs alone (include/vp_hip.h, vp_multi.h, vp_host.h).
+// Feeds are sharded over the devices (feed i of device g has the seed feed_seed(g, i) of vision-processor_amd/feeds.py and the camera id
+// g * feeds + i).  ONE DRIVER THREAD PER DEVICE with its own context, two streams, two sets of frame buffers (vp_frame_buffers_create) and -- with
+// --detect -- its own detectors and host threads:
+//     step k on stream k & 1:  vp_frame -> vp_records_compact -> (detect: read-back of the compact slots)
+//     detect, for step k - 1 while the GPU works on step k:  vph_detect_batch_slots -> packet block -> copy into the device's gather block
+// and ONE grouped RCCL all-gather per step (vp_gather_start, issued by the thread that reaches the step's rendezvous last) hands every device every
+// device's block -- the encoded SSL_WrapperPackets with --detect, the compact blob records without -- on the gather streams, beside the next step's
+// kernels.  This replaces the reference's per-camera processes (one loop per camera, src/main.cpp:262-317; hypotheses -> SSL_WrapperPacket,
+// main.cpp:319-370) exchanging packets over UDP multicast (src/udpsocket.cpp:94-100 send, :147-163 receive).
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "vp_hip.h"
+#include "vp_host.h"
 #include "vp_multi.h"
 
 #define CK(call) \
@@ -25,111 +33,306 @@
 
 void vp_feeds_cfg2_params(VpFrameParams* p); // feeds_main.cpp
 
-int vp_feeds_run_multi(int gpus, int feeds, int steps, int warmup, int verify, int local) {
+struct MultiOptions {
+	int gpus = 1, feeds = 128, steps = 20, warmup = 3;
+	int verify = 0, local = 0, detect = 0, threads = 16, cap = 192, full = 0;
+	const char* dump = nullptr;
+};
+
+namespace {
+
+// every driver thread arrives once per step; the last one runs `last()` (the grouped gather) before anyone is released
+class Rendezvous {
+	std::mutex mu;
+	std::condition_variable cv;
+	int n, waiting = 0;
+	unsigned long generation = 0;
+public:
+	explicit Rendezvous(int n_): n(n_) {}
+	template<typename F> void arrive(F last) {
+		std::unique_lock<std::mutex> lk(mu);
+		if(++waiting == n) {
+			last();
+			waiting = 0;
+			generation++;
+			cv.notify_all();
+			return;
+		}
+		const unsigned long g = generation;
+		cv.wait(lk, [&] { return generation != g; });
+	}
+};
+
+struct Dev {
+	int g = 0;
+	VpContext* ctx = nullptr;
+	uint8_t* dRaw = nullptr;
+	VpFrameSlab* slab[2] = {nullptr, nullptr};
+	VpFrameBuffers buf[2];
+	uint8_t* dSlots[2] = {nullptr, nullptr}; // detect: compact record slots of a step (device), read back into hSlots
+	void* hSlots[2] = {nullptr, nullptr};
+	void* hPackets[2] = {nullptr, nullptr};
+	std::vector<VphDetector*> det;
+	long blobs = 0, packetBytes = 0, robots = 0, balls = 0;
+	double stageMs = 0, waitMs = 0;
+	VpPlacement place[2];
+};
+
+} // namespace
+
+int vp_feeds_run_multi(const MultiOptions& o) {
 	const int visible = vp_device_count();
-	if(gpus < 1 || gpus > visible) {
-		fprintf(stderr, "[FATAL] --gpus %d but %d HIP device(s) are visible\n", gpus, visible);
+	if(o.gpus < 1 || o.gpus > visible) {
+		fprintf(stderr, "[FATAL] --gpus %d but %d HIP device(s) are visible\n", o.gpus, visible);
 		return 1;
 	}
 	VpFrameParams p;
 	vp_feeds_cfg2_params(&p);
-	if(local) p.sat_variant = VP_SAT_LOCAL; // no global table: resampling + ONE kernel per step and device
-	const int qw = p.qw, qh = p.qh, mm = p.max_matches;
-	const size_t rawBytes = (size_t)4 * qw * qh, npx = (size_t)p.fw * p.fh;
-	size_t offC = 0, offM = 0, offI = 0;
-	const size_t recBytes = vp_record_layout(feeds, mm, &offC, &offM, &offI);
+	if(o.local) p.sat_variant = VP_SAT_LOCAL; // no global table: resampling + ONE kernel per step and device
+	const int N = o.gpus, feeds = o.feeds, mm = p.max_matches, packetSlot = 4096;
+	const size_t rawBytes = (size_t)4 * p.qw * p.qh;
+	// what a device contributes per step
+	size_t offC = 0, offM = 0, offI = 0, slotBytes = 0;
+	const size_t fullBytes = vp_record_layout(feeds, mm, &offC, &offM, &offI);
+	const size_t compactBytes = vp_record_layout_compact(feeds, o.cap, &slotBytes, nullptr, nullptr);
+	const size_t packetBytes = vp_packet_layout(feeds, packetSlot);
+	const size_t blockBytes = o.detect ? packetBytes : (o.full ? fullBytes : compactBytes);
+	const char* blockKind = o.detect ? "SSL_WrapperPacket slots" : (o.full ? "full records" : "compact records");
 
-	std::vector<int> devs(gpus);
-	for(int g = 0; g < gpus; g++) devs[g] = g;
+	std::vector<int> devs(N);
+	for(int g = 0; g < N; g++) devs[g] = g;
 	VpGather* gather = nullptr;
-	CK(vp_gather_create(gpus, devs.data(), recBytes, 2, &gather));
-	std::vector<VpContext*> ctx(gpus, nullptr);
-	std::vector<uint8_t*> dRaw(gpus, nullptr);
-	std::vector<VpFrameBuffers> buf((size_t)gpus * 2);
+	CK(vp_gather_create(N, devs.data(), blockBytes, 2, &gather));
+	std::vector<Dev> dev(N);
+	std::vector<VpContext*> ctxs(N, nullptr);
+	const int threadsPerDev = std::max(1, o.threads / N);
+	const float calibBase[8] = {p.model.f, p.model.p[0], p.model.p[1], p.model.d, -1.f, 0.f, 0.f, 0.f};
+	const int32_t field[5] = {9000, 6000, 300, -1, 10};
+
+	// set-up, one thread per device (rendering the synthetic feeds is the slow part)
 	{
-		std::vector<uint8_t> frame(rawBytes);
-		for(int g = 0; g < gpus; g++) {
-			CK(vp_ctx_create(g, 2, &ctx[g]));
-			CK(vp_malloc_device(ctx[g], rawBytes * feeds, (void**)&dRaw[g]));
-			for(int i = 0; i < feeds; i++) { // feeds.py feed_seed(rank, frame) = rank * 100000 + frame
-				CK(vp_synth_frame(&p.model, p.layout, qw, qh, p.max_robot_height, 9000.f, 6000.f, 0x5EED0000u + (uint32_t)(g * 100000 + i), 16, 8, 3.0f, frame.data()));
-				CK(vp_copy_h2d(ctx[g], 0, dRaw[g] + rawBytes * i, frame.data(), rawBytes));
-				CK(vp_sync(ctx[g], 0));
-			}
-			for(int s = 0; s < 2; s++) {
-				VpFrameBuffers& b = buf[(size_t)g * 2 + s];
-				memset(&b, 0, sizeof(b));
-				CK(vp_malloc_device(ctx[g], npx * 4 * feeds, (void**)&b.flat));
-				if(!local) CK(vp_malloc_device(ctx[g], npx * 4 * feeds, (void**)&b.sat));
-				uint8_t* rec = static_cast<uint8_t*>(vp_gather_send(gather, g, s)); // vp_frame writes its outputs into the record block itself
-				b.counter = reinterpret_cast<int32_t*>(rec + offC);
-				b.matches = reinterpret_cast<VpMatch*>(rec + offM);
-				b.idx = reinterpret_cast<uint32_t*>(rec + offI);
-			}
-		}
+		std::vector<std::thread> th;
+		for(int g = 0; g < N; g++)
+			th.emplace_back([&, g] {
+				Dev& d = dev[g];
+				d.g = g;
+				CK(vp_ctx_create(g, 2, &d.ctx));
+				ctxs[g] = d.ctx;
+				CK(vp_malloc_device(d.ctx, rawBytes * feeds, (void**)&d.dRaw));
+				std::vector<uint8_t> frame(rawBytes);
+				for(int i = 0; i < feeds; i++) { // feeds.py feed_seed(rank, frame) = rank * 100000 + frame
+					CK(vp_synth_frame(&p.model, p.layout, p.qw, p.qh, p.max_robot_height, 9000.f, 6000.f, 0x5EED0000u + (uint32_t)(g * 100000 + i), 16, 8, 3.0f, frame.data()));
+					CK(vp_copy_h2d(d.ctx, 0, d.dRaw + rawBytes * i, frame.data(), rawBytes));
+					CK(vp_sync(d.ctx, 0));
+				}
+				for(int s = 0; s < 2; s++) {
+					CK(vp_frame_buffers_create(d.ctx, &p, feeds, 0, &d.buf[s], &d.slab[s]));
+					if(o.full && !o.detect) { // vp_frame writes its outputs into the gather block itself
+						uint8_t* rec = static_cast<uint8_t*>(vp_gather_send(gather, g, s));
+						d.buf[s].counter = reinterpret_cast<int32_t*>(rec + offC);
+						d.buf[s].matches = reinterpret_cast<VpMatch*>(rec + offM);
+						d.buf[s].idx = reinterpret_cast<uint32_t*>(rec + offI);
+					}
+					if(o.detect) {
+						CK(vp_malloc_device(d.ctx, compactBytes, (void**)&d.dSlots[s]));
+						CK(vp_malloc_host(d.ctx, compactBytes, &d.hSlots[s]));
+						CK(vp_malloc_host(d.ctx, packetBytes, &d.hPackets[s]));
+						memset(d.hPackets[s], 0, packetBytes);
+					}
+				}
+				CK(vp_frame_buffers_placement(d.slab[0], &d.place[0], &d.place[1]));
+				if(o.detect) {
+					const float calib[11] = {calibBase[0], calibBase[1], calibBase[2], calibBase[3], calibBase[4], calibBase[5], calibBase[6], calibBase[7], -p.model.c[0], p.model.c[1],
+							p.model.c[2]}; // nadir: t = R (-pos)
+					for(int i = 0; i < feeds; i++) {
+						VphConfig cfg;
+						vph_config_defaults(&cfg);
+						cfg.cam_id = g * feeds + i; // every feed is its own camera: own colour model, own tracker
+						VphDetector* dt = vph_detector_create(&cfg);
+						if(!dt || vph_detector_set_geometry_direct(dt, calib, p.qw, p.qh, p.field_scale, p.off_x, p.off_y, p.fw, p.fh, field, 21.5f, 90.f, nullptr, 0, nullptr, 0) != VP_OK) {
+							fprintf(stderr, "[FATAL] detector %d of device %d\n", i, g);
+							exit(1);
+						}
+						d.det.push_back(dt);
+					}
+				}
+			});
+		for(std::thread& t : th) t.join();
 	}
-	std::vector<int> streams(gpus, 0);
-	auto step = [&](int k) {
-		const int s = k & 1;
-		CK(vp_gather_wait(gather, s)); // the gather issued two steps ago has released this slot's send block
-		for(int g = 0; g < gpus; g++) {
-			CK(vp_frame(ctx[g], s, &p, dRaw[g], feeds, &buf[(size_t)g * 2 + s]));
-			streams[g] = s;
-		}
-		CK(vp_gather_start(gather, s, ctx.data(), streams.data()));
+
+	Rendezvous meet(N);
+	std::vector<int> gstreams(N, 0);
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	const int total = o.warmup + o.steps;
+	std::chrono::steady_clock::time_point t0, t1;
+
+	// The gather of slot s for step j is started by the last thread to reach the rendezvous; it records an event on every device's stream s, so all
+	// work queued there so far (vp_frame + compaction, or the packet copy) precedes it.
+	auto gatherSlot = [&](int s) {
+		meet.arrive([&] {
+			for(int g = 0; g < N; g++) gstreams[g] = s;
+			CK(vp_gather_start(gather, s, ctxs.data(), gstreams.data()));
+		});
 	};
-	int k = 0;
-	for(; k < warmup; k++) step(k);
-	CK(vp_gather_wait(gather, 0));
-	CK(vp_gather_wait(gather, 1));
-	for(int g = 0; g < gpus; g++) CK(vp_sync(ctx[g], -1));
-	const auto t0 = std::chrono::steady_clock::now();
-	for(int j = 0; j < steps; j++, k++) step(k);
-	CK(vp_gather_wait(gather, 0)); // every step's gather has completed inside the timed region
-	CK(vp_gather_wait(gather, 1));
-	for(int g = 0; g < gpus; g++) CK(vp_sync(ctx[g], -1));
-	const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	auto driver = [&](int g) {
+		Dev& d = dev[g];
+		auto launch = [&](int k) { // step k (0-based) on stream / buffer set k & 1
+			const int s = k & 1;
+			CK(vp_frame(d.ctx, s, &p, d.dRaw, feeds, &d.buf[s]));
+			if(o.detect) {
+				CK(vp_records_compact(d.ctx, s, d.buf[s].counter, d.buf[s].matches, nullptr, feeds, mm, o.cap, d.dSlots[s]));
+				CK(vp_copy_d2h(d.ctx, s, d.hSlots[s], d.dSlots[s], compactBytes));
+			} else if(!o.full) {
+				CK(vp_records_compact(d.ctx, s, d.buf[s].counter, d.buf[s].matches, d.buf[s].idx, feeds, mm, o.cap, static_cast<uint8_t*>(vp_gather_send(gather, g, s))));
+			}
+		};
+		auto cpuStage = [&](int k, bool timed) { // step k's blobs -> packets -> this device's gather block of slot k & 1
+			const int s = k & 1;
+			const auto w0 = now();
+			CK(vp_sync(d.ctx, s)); // the read-back of step k has landed
+			const auto w1 = now();
+			const uint32_t frameNo = (uint32_t)k + 1; // steps are numbered from 1
+			const double t = frameNo / 70.0;
+			const int rc = vph_detect_batch_slots(d.det.data(), feeds, static_cast<const uint8_t*>(d.hSlots[s]), slotBytes, mm, frameNo, t, t, t + 0.002, threadsPerDev,
+					static_cast<uint8_t*>(d.hPackets[s]), packetSlot);
+			if(rc != VP_OK) {
+				fprintf(stderr, "[FATAL] device %d step %d: the CPU stage refused the record slots (a frame has more than --cap %d blobs?)\n", g, k, o.cap);
+				exit(1);
+			}
+			CK(vp_gather_wait(gather, s)); // the gather issued two steps ago has released this slot's block
+			CK(vp_copy_h2d(d.ctx, s, vp_gather_send(gather, g, s), d.hPackets[s], packetBytes));
+			if(timed) {
+				d.waitMs += ms(w0, w1);
+				d.stageMs += ms(w1, now());
+				for(int i = 0; i < feeds; i++) {
+					int32_t head[4], len;
+					memcpy(head, static_cast<const uint8_t*>(d.hSlots[s]) + (size_t)i * slotBytes, sizeof(head));
+					memcpy(&len, static_cast<const uint8_t*>(d.hPackets[s]) + (size_t)i * packetSlot, 4);
+					d.blobs += head[3];
+					d.packetBytes += len > 0 ? len : 0;
+				}
+			}
+		};
+		for(int k = 0; k < total; k++) {
+			if(k == o.warmup) { // everything issued so far completes, then all devices start the clock together
+				if(o.detect && k > 0) {
+					cpuStage(k - 1, false);
+					gatherSlot((k - 1) & 1);
+				}
+				CK(vp_gather_wait(gather, 0));
+				CK(vp_gather_wait(gather, 1));
+				CK(vp_sync(d.ctx, -1));
+				meet.arrive([&] { t0 = now(); });
+			}
+			const int s = k & 1;
+			if(!o.detect) CK(vp_gather_wait(gather, s)); // the gather issued two steps ago has released this slot's block (vp_frame / the compaction write into it)
+			launch(k);
+			if(!o.detect) {
+				gatherSlot(s);
+			} else if(k > 0 && k != o.warmup) {
+				cpuStage(k - 1, k - 1 >= o.warmup); // the previous step's CPU stage while the GPU works on this one
+				gatherSlot((k - 1) & 1);
+			}
+		}
+		if(o.detect) { // the last step's CPU stage has no following GPU step to hide behind
+			cpuStage(total - 1, total - 1 >= o.warmup);
+			gatherSlot((total - 1) & 1);
+		}
+		CK(vp_gather_wait(gather, 0)); // every step's gather has completed inside the timed region
+		CK(vp_gather_wait(gather, 1));
+		CK(vp_sync(d.ctx, -1));
+		meet.arrive([&] { t1 = now(); });
+	};
+	{
+		std::vector<std::thread> th;
+		for(int g = 0; g < N; g++) th.emplace_back(driver, g);
+		for(std::thread& t : th) t.join();
+	}
+	const double dt = std::chrono::duration<double>(t1 - t0).count();
 
 	// what the last step gathered: every device holds every device's block, byte for byte what the owners produced
-	const int last = (k - 1) & 1;
+	const int last = (total - 1) & 1;
 	int verified = -1;
-	std::vector<uint8_t> own((size_t)gpus * recBytes), got((size_t)gpus * recBytes);
-	for(int g = 0; g < gpus; g++) CK(vp_copy_d2h_sync(ctx[g], 0, own.data() + (size_t)g * recBytes, vp_gather_send(gather, g, last), recBytes));
-	if(verify) {
+	std::vector<uint8_t> own((size_t)N * blockBytes), got((size_t)N * blockBytes);
+	for(int g = 0; g < N; g++) CK(vp_copy_d2h_sync(dev[g].ctx, 0, own.data() + (size_t)g * blockBytes, vp_gather_send(gather, g, last), blockBytes));
+	if(o.verify) {
 		verified = 1;
-		for(int g = 0; g < gpus; g++) {
-			CK(vp_copy_d2h_sync(ctx[g], 0, got.data(), vp_gather_recv(gather, g, last), (size_t)gpus * recBytes));
-			if(memcmp(got.data(), own.data(), (size_t)gpus * recBytes) != 0) {
-				fprintf(stderr, "[FATAL] device %d received records that differ from what their owners produced\n", g);
+		for(int g = 0; g < N; g++) {
+			CK(vp_copy_d2h_sync(dev[g].ctx, 0, got.data(), vp_gather_recv(gather, g, last), (size_t)N * blockBytes));
+			if(memcmp(got.data(), own.data(), (size_t)N * blockBytes) != 0) {
+				fprintf(stderr, "[FATAL] device %d received blocks that differ from what their owners produced\n", g);
 				verified = 0;
 			}
 		}
 	}
-	long blobs = 0;
-	printf("{\"program\": \"vp_feeds\", \"gpus\": %d, \"feeds_per_gpu\": %d, \"steps\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"record_bytes_per_gpu\": %zu, \"gather\": \"RCCL ncclAllGather, one grouped call per step, %d rank(s) in one process\", \"sat_variant\": \"%s\"",
-			gpus, feeds, steps, (double)gpus * feeds * steps / dt, 1e3 * dt / steps, recBytes, gpus, local ? "local" : "tiled");
-	printf(", \"counters\": [");
-	for(int g = 0; g < gpus; g++) {
-		const int32_t* c = reinterpret_cast<const int32_t*>(own.data() + (size_t)g * recBytes + offC);
-		printf("%s[", g ? ", " : "");
-		for(int i = 0; i < feeds; i++) {
-			printf("%s[%d, %d, %d]", i ? ", " : "", c[3 * i], c[3 * i + 1], c[3 * i + 2]);
-			blobs += c[3 * i] < mm ? c[3 * i] : mm;
+	if(o.dump) { // what the LAST device received in the last step: N blocks in rank order
+		CK(vp_copy_d2h_sync(dev[N - 1].ctx, 0, got.data(), vp_gather_recv(gather, N - 1, last), (size_t)N * blockBytes));
+		FILE* f = fopen(o.dump, "wb");
+		if(!f || fwrite(got.data(), 1, (size_t)N * blockBytes, f) != (size_t)N * blockBytes) {
+			fprintf(stderr, "[FATAL] cannot write %s\n", o.dump);
+			return 1;
 		}
-		printf("]");
+		fclose(f);
 	}
-	printf("], \"blobs_per_frame\": %.2f", blobs / ((double)gpus * feeds));
-	if(verify) printf(", \"gather_verified\": %s", verified == 1 ? "true" : "false");
+
+	long blobs = 0;
+	printf("{\"program\": \"vp_feeds\", \"gpus\": %d, \"feeds_per_gpu\": %d, \"steps\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"record_bytes_per_gpu\": %zu, \"block\": \"%s\", "
+		   "\"full_record_bytes_per_gpu\": %zu, \"gather\": \"RCCL ncclAllGather, one grouped call per step, %d rank(s) in one process, one driver thread per device\", \"sat_variant\": \"%s\"",
+			N, feeds, o.steps, (double)N * feeds * o.steps / dt, 1e3 * dt / o.steps, blockBytes, blockKind, fullBytes, N, o.local ? "local" : "tiled");
+	if(o.detect) {
+		long robots = 0, balls = 0, pbytes = 0;
+		double stage = 0, wait = 0;
+		for(Dev& d : dev) {
+			for(VphDetector* dt2 : d.det) {
+				VphFrameHeader h;
+				vph_frame_header(dt2, &h);
+				robots += h.n_robots_yellow + h.n_robots_blue;
+				balls += h.n_balls;
+			}
+			blobs += d.blobs;
+			pbytes += d.packetBytes;
+			stage += d.stageMs;
+			wait += d.waitMs;
+		}
+		printf(", \"detect\": {\"host_threads_per_gpu\": %d, \"robots_per_frame\": %.3f, \"balls_per_frame\": %.3f, \"packet_bytes_per_frame\": %.1f, \"packet_slot_bytes\": %d, "
+			   "\"host_ms_per_step\": {\"wait_for_gpu\": %.3f, \"cpu_stage\": %.3f}, \"rendered\": {\"robots\": 16, \"balls\": 8}}, \"blobs_per_frame\": %.2f",
+				threadsPerDev, robots / ((double)N * feeds), balls / ((double)N * feeds), pbytes / ((double)N * feeds * o.steps), packetSlot, wait / N / o.steps, stage / N / o.steps,
+				blobs / ((double)N * feeds * o.steps));
+	} else {
+		printf(", \"counters\": [");
+		for(int g = 0; g < N; g++) {
+			printf("%s[", g ? ", " : "");
+			for(int i = 0; i < feeds; i++) {
+				int32_t c[4];
+				if(o.full) memcpy(c, own.data() + (size_t)g * blockBytes + offC + 12 * (size_t)i, 12);
+				else memcpy(c, own.data() + (size_t)g * blockBytes + (size_t)i * slotBytes, 16);
+				printf("%s[%d, %d, %d]", i ? ", " : "", c[0], c[1], c[2]);
+				blobs += c[0] < mm ? c[0] : mm;
+			}
+			printf("]");
+		}
+		printf("], \"blobs_per_frame\": %.2f", blobs / ((double)N * feeds));
+	}
+	printf(", \"placement\": {\"sat_write_gbs\": [");
+	for(int g = 0; g < N; g++) printf("%s%.0f", g ? ", " : "", dev[g].place[0].write_gbs);
+	printf("], \"candidates\": [");
+	for(int g = 0; g < N; g++) printf("%s%d", g ? ", " : "", dev[g].place[0].candidates + 0);
+	printf("]}");
+	if(o.verify) printf(", \"gather_verified\": %s", verified == 1 ? "true" : "false");
 	printf("}\n");
 
-	for(int g = 0; g < gpus; g++) {
+	for(Dev& d : dev) {
+		for(VphDetector* dt2 : d.det) vph_detector_destroy(dt2);
 		for(int s = 0; s < 2; s++) {
-			vp_free_device(ctx[g], buf[(size_t)g * 2 + s].flat);
-			vp_free_device(ctx[g], buf[(size_t)g * 2 + s].sat);
+			vp_frame_buffers_destroy(d.ctx, d.slab[s]);
+			if(d.dSlots[s]) vp_free_device(d.ctx, d.dSlots[s]);
+			if(d.hSlots[s]) vp_free_host(d.ctx, d.hSlots[s]);
+			if(d.hPackets[s]) vp_free_host(d.ctx, d.hPackets[s]);
 		}
-		vp_free_device(ctx[g], dRaw[g]);
+		vp_free_device(d.ctx, d.dRaw);
 	}
 	vp_gather_destroy(gather);
-	for(int g = 0; g < gpus; g++) vp_ctx_destroy(ctx[g]);
+	for(Dev& d : dev) vp_ctx_destroy(d.ctx);
 	return verified == 0 ? 1 : 0;
 }
