@@ -182,6 +182,21 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
                 continue
             local[str(b)] = round(rate(lambda: ctx.frame(p_local, d_raw, b, flat, None, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
         out["frames_per_s_sat_local_variant"] = local
+        # the other candidate of the unpinned sampler (resampling.cl:50): NEAREST through the same staged kernel family
+        if cfg.sampler_mode != 0:
+            p_near = capi.frame_params(cfg, sat_variant=params.sat_variant, order=params.order, sampler_mode=0)
+            near_rate = round(rate(lambda: ctx.frame(p_near, d_raw, B, flat, sat, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // B)), B), 1)
+            ctx.events_clear()
+            ctx.events_enable(True)
+            for _ in range(5):
+                ctx.frame(p_near, d_raw, B, flat, sat, matches, counter, idx=idx, stream=0)
+            ctx.events_enable(False)
+            st = {}
+            for name, ms in ctx.event_times():
+                st.setdefault(name, []).append(ms)
+            ctx.events_clear()
+            out["frames_per_s_sampler_nearest"] = near_rate
+            out["stage_ms_sampler_nearest"] = {k: round(float(np.mean(v)), 4) for k, v in st.items()}
         ctx.frame(params, d_raw, B, flat, sat, matches, counter, idx=idx, stream=0)  # leave the default path's outputs in the buffers
         ctx.sync()
         # one frame, host-synchronised after every frame: latency of the whole hot path
@@ -390,6 +405,8 @@ def main():
     ap.add_argument("--sat", default="tiled", choices=["tiled", "twopass", "local"], help="tiled = the single-pass SAT the roofline is quoted on (default); twopass = global-recursive comparison; "
                     "local = optional variant without a global table (one fused kernel after resampling)")
     ap.add_argument("--order", default="raster", choices=["raster", "atomic"])
+    ap.add_argument("--sampler", default="bilinear", choices=["bilinear", "nearest"], help="what read_imageui through CLK_FILTER_LINEAR on an integer image returns (resampling.cl:50; OpenCL leaves "
+                    "it undefined, SURVEY H1): bilinear = spec 8.2 formula truncated (default, the headline), nearest = point sampling")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bounded CPU sample, per baseline (reference kernels and port)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detect", action="store_true", help="BASELINE config 4 in full: additionally run the CPU hypothesis stage (main.cpp:319-370, one detector per feed "
@@ -439,6 +456,8 @@ def main():
     vp = load()
     capi = vp.load_capi()
     cfg = vp.configs.ALL[args.workload]
+    if args.sampler == "nearest":  # the other reading of resampling.cl:50: everything below -- kernels, oracle check, CPU baseline -- follows
+        cfg = cfg.with_(sampler_mode=vp.configs.SAMPLER_NEAREST)
     B, mm = args.batch, cfg.max_matches
     ctx = capi.Context(local_rank, stream_ptr=torch.cuda.current_stream().cuda_stream)
     params = capi.frame_params(cfg, sat_variant={"tiled": capi.SAT_TILED, "twopass": capi.SAT_TWOPASS, "local": capi.SAT_LOCAL}[args.sat],
@@ -591,7 +610,7 @@ def main():
             "dtype": "u8/int32 (fp32 for coordinates and scores)", "data": "synthetic",
             "config": {"workload": cfg.name, "frames_per_step_per_gpu": B, "sensor": "2048x1536 RGGB8", "flat": f"{cfg.fw}x{cfg.fh}", "grad_offset": cfg.grad_offset,
                        "circle_radius": cfg.circle_radius, "list_radius": cfg.list_radius, "max_blobs": mm, "sat_variant": args.sat, "list_order": args.order,
-                       "sampler": "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (f", {coll} all-gather of detection records per step" if dist else "")},
+                       "sampler": "NEAREST" if args.sampler == "nearest" else "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (f", {coll} all-gather of detection records per step" if dist else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": roof_kernel, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},
             "stage_ms_per_step": {k: round(float(np.mean(v)), 4) for k, v in stage_ms.items()},
