@@ -244,6 +244,25 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
             pcie(kk[0])
             kk[0] += 1
         out["frames_per_s_pcie_inclusive"] = round(rate(pcie_step, 40, g), 1)
+        # the same with vp_ctx_tune "frame_graph" = 1: the three launches of a repeated vp_frame call replayed as one captured hipGraph
+        ctx.tune("frame_graph", 1)
+        for _ in range(3):
+            ctx.frame(params, d_raw, 1, flat, sat, matches, counter, idx=idx, stream=0)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.frame(params, d_raw, 1, flat, sat, matches, counter, idx=idx, stream=0)
+            ctx.sync(0)
+        out["single_frame_latency_us_frame_graph"] = round(1e6 * (time.perf_counter() - t0) / n, 1)
+        gstreams = {}
+        for ns, b in ((1, 1), (8, 1), (8, 8)):
+            def go():
+                for st in range(ns):
+                    u = bufs[st]
+                    ctx.frame(params, d_raw[st * b:], b, u["flat"], u["sat"], u["m"], u["c"], idx=u["i"], stream=st)
+            gstreams[f"{ns}x{b}"] = round(rate(go, 100 if b == 1 else 30, ns * b), 1)
+        out["frames_per_s_streams_x_frames_per_launch_frame_graph"] = gstreams
+        ctx.tune("frame_graph", 0)
         out["note"] = "measured after the timed region on the same resident frames (PCIe figure: host-pinned frames copied in, records copied out); none of these is `value`"
     finally:
         ctx.close()

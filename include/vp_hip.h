@@ -91,7 +91,9 @@ const char* vp_device_name(VpContext* ctx);
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
  *   write the dense halo strips the tiled SAT pass reads), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
- *   request; 0 or 1 = take what hipMalloc gives).  Applies to calls issued after it. */
+ *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 (default 0: vp_frame captures the launches of a repeated (stream, parameters, batch,
+ *   buffers) call into a hipGraph the second time it sees it and replays the graph from then on; calls with stage events enabled or debug views take the
+ *   ordinary path).  Applies to calls issued after it. */
 int vp_ctx_tune(VpContext* ctx, const char* key, int value);
 
 /* per-launch timing, the analogue of the stored cl::Event list (opencl.h:84, opencl.cpp:94-105).  When enabled every

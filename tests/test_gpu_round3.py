@@ -331,3 +331,60 @@ def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
             S.assert_frames_equal(got, want)
             assert d.t_sent == total / 70.0 + 0.002
             assert len(d.robots_yellow) + len(d.robots_blue) == 16
+
+
+@pytest.mark.parametrize("variant", ["tiled", "local"])
+def test_frame_graph_replay_is_result_neutral(env, port, variant):
+    """vp_ctx_tune "frame_graph": vp_frame captures the launches of a repeated (stream, parameters, batch, buffers) call into a hipGraph the second
+    time it sees it and replays it afterwards (nothing that changes between calls is a kernel argument: the single-pass SAT derives its epoch and
+    ticket base from the tickets it draws).  Four library-owned streams, two geometries taking turns on every stream (a replay must notice that the
+    stream's coordinate map was rebuilt for the other geometry and that the SAT shape changed), eight rounds, new sensor frames written into the same
+    device buffers between rounds: every result equals the CPU oracle's -- flat, SAT, counters, sorted records.  One loop per camera: main.cpp:262-317."""
+    capi, torch = env
+    cfg_a, cfg_b = cfgs.T_MID, cfgs.T_MID.with_(name="t_mid_shifted", off_x=-1400.0, off_y=-850.0)
+    NS, B = 4, 2
+    with_sat = variant == "tiled"
+    sv = capi.SAT_TILED if with_sat else capi.SAT_LOCAL
+    ctx = capi.Context(0, n_streams=NS)
+    try:
+        ctx.tune("frame_graph", 1)
+        model_o = {c.name: O.CameraModel.from_array(np.frombuffer(bytes(c.model()), np.uint8)) for c in (cfg_a, cfg_b)}
+
+        def want(cfg, raw):
+            mm = cfg.max_matches
+            s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+            m, idx, cnt = port.frame(raw, cfg.layout, cfg.qw, cfg.qh, model_o[cfg.name], cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                     cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+            return dict(flat=s["flat"].copy(), sat=port.sat_i32(s["graddot"])[0], m=m, idx=idx, cnt=cnt)
+
+        mm = cfg_a.max_matches
+        bufs = []
+        for s in range(NS):
+            bufs.append({c.name: dict(raw=torch.zeros((B,) + c.sensor_shape, dtype=torch.uint8, device="cuda"), flat=torch.zeros((B, c.fh, c.fw, 4), dtype=torch.uint8, device="cuda"),
+                                      sat=torch.zeros((B, c.fh, c.fw), dtype=torch.int32, device="cuda") if with_sat else None, m=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"),
+                                      idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"), cnt=torch.full((B, 3), -5, dtype=torch.int32, device="cuda")) for c in (cfg_a, cfg_b)})
+        params = {c.name: capi.frame_params(c, sat_variant=sv, order=capi.ORDER_RASTER) for c in (cfg_a, cfg_b)}
+        for rnd in range(8):
+            # rounds 0-3: geometry A only (ordinary call, capture, replay, replay); then B and A take turns on every stream
+            cfg = cfg_a if rnd < 4 or rnd % 2 == 0 else cfg_b
+            raws = [[cfg.synth(7000 + 100 * rnd + 10 * s + k) for k in range(B)] for s in range(NS)]
+            for s in range(NS):
+                bufs[s][cfg.name]["raw"].copy_(torch.from_numpy(np.stack(raws[s])))
+            torch.cuda.synchronize()
+            for s in range(NS):  # every stream is loaded before any of them is waited for
+                b = bufs[s][cfg.name]
+                ctx.frame(params[cfg.name], b["raw"], B, b["flat"], b["sat"], b["m"], b["cnt"], idx=b["idx"], stream=s)
+            ctx.sync()
+            for s in range(NS):
+                b = bufs[s][cfg.name]
+                for k in range(B):
+                    w_ = want(cfg, raws[s][k])
+                    assert np.array_equal(b["flat"][k].cpu().numpy(), w_["flat"]), (rnd, s, k, "flat")
+                    if with_sat:
+                        assert np.array_equal(b["sat"][k].cpu().numpy(), w_["sat"]), (rnd, s, k, "sat")
+                    cnt = b["cnt"][k].cpu().numpy()
+                    assert np.array_equal(cnt, w_["cnt"]), (rnd, s, k, cnt, w_["cnt"])
+                    n = min(int(cnt[0]), mm)
+                    assert np.array_equal(b["idx"][k].cpu().numpy().view(np.uint32)[:n], w_["idx"]) and b["m"][k].cpu().numpy()[:22 * n].tobytes() == w_["m"].tobytes(), (rnd, s, k)
+    finally:
+        ctx.close()

@@ -49,7 +49,19 @@ struct VpTuning {
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
+	int frame_graph = 0;           // vp_frame replays a captured hipGraph of its launches for a repeated (stream, parameters, batch, buffers) tuple
 	int placement_candidates = 48; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives)
+};
+
+// one captured vp_frame launch sequence (vp_frame.hip, vp_ctx_tune "frame_graph")
+struct VpFrameGraph {
+	std::vector<uint8_t> key; // stream, batch, parameters, raw pointer, buffers, tuning
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+	bool failed = false;       // capture was refused once: this tuple stays on the ordinary path
+	uint64_t ws_generation = 0, sat_shape = 0;
+	uint32_t sat_tickets = 0;
+	unsigned char map_key[96] = {};
 };
 
 struct VpContext {
@@ -60,9 +72,12 @@ struct VpContext {
 	VpWorkspace ws[5][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, append-order records); slot 1: persistent SAT tile carries; slot 2: coordinate map; slot 3: halo strips;
 	                                     // slot 4: self-cleaning counters of the blob list (zero between launches: nothing else may ever be placed there)
 	unsigned char map_key[VP_MAX_STREAMS][96] = {}; // geometry the cached coordinate map of each stream was built for
-	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // generation tag of the single-pass SAT carry granules
-	uint32_t sat_ticket_base[VP_MAX_STREAMS] = {}; // tickets handed out per frame queue by all earlier launches on this stream (mod 2^32)
-	uint64_t sat_shape[VP_MAX_STREAMS] = {};       // tiling + batch those counters were advanced with
+	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // single-pass SAT launches on this stream since its carry state was last reset (the kernels derive the same number from their tickets)
+	uint64_t sat_shape[VP_MAX_STREAMS] = {};       // tiling + batch + tickets per launch those launches were made with
+	uint32_t sat_tickets[VP_MAX_STREAMS] = {};     // tickets per launch and frame queue of that shape
+	uint64_t ws_generation[VP_MAX_STREAMS] = {};   // bumped whenever a workspace of the stream is (re)allocated: captured graphs hold the old pointers
+	bool capturing[VP_MAX_STREAMS] = {};           // a vp_frame launch sequence is being captured on the stream: nothing may synchronise, allocate or reset
+	std::vector<VpFrameGraph> graphs;
 	int* host_flag[VP_MAX_STREAMS] = {};           // pinned, device-mapped word the SAT kernel raises on a look-back timeout
 	std::string device_name;
 	int cu_count = 0;
@@ -114,6 +129,7 @@ static inline int vp_check_ctx(VpContext* ctx, int stream) {
 // *grew (optional) tells the caller that persistent contents were lost.
 int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out, bool* grew = nullptr);
 
+void vp_frame_graphs_clear(VpContext* ctx); // vp_frame.hip
 // vp_alloc.hip
 int vp_probe_stream_impl(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us);
 #define VP_PLACEMENT_FAST_GBS 4700.f // zero-fill rate that separates the two populations of 1.6 GB allocations on MI355X (4.95-5.4 vs 3.8-4.4 TB/s)

@@ -91,6 +91,7 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 		(void)hipEventDestroy(e.start);
 		(void)hipEventDestroy(e.stop);
 	}
+	vp_frame_graphs_clear(ctx);
 	for(VpImage* im : ctx->image_pool) {
 		if(im->buf.dev) (void)hipFree(im->buf.dev);
 		if(im->buf.host) (void)hipHostFree(im->buf.host);
@@ -120,6 +121,10 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 	} else if(k == "sat_halo_strips") {
 		VP_REQUIRE(value == 0 || value == 1, "vp_ctx_tune: sat_halo_strips is 0 or 1");
 		ctx->tune.sat_halo_strips = value;
+	} else if(k == "frame_graph") {
+		VP_REQUIRE(value == 0 || value == 1, "vp_ctx_tune: frame_graph is 0 or 1");
+		ctx->tune.frame_graph = value;
+		if(!value) vp_frame_graphs_clear(ctx);
 	} else if(k == "placement_candidates") {
 		VP_REQUIRE(value >= 0 && value <= 256, "vp_ctx_tune: placement_candidates out of range [0,256]");
 		ctx->tune.placement_candidates = value;
@@ -160,6 +165,11 @@ int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out,
 	VpWorkspace& w = ctx->ws[slot][stream];
 	if(grew) *grew = false;
 	if(w.bytes < bytes) {
+		if(ctx->capturing[stream]) {
+			vp_set_error("a workspace would have to grow inside a graph capture");
+			return VP_ERR_INVALID;
+		}
+		ctx->ws_generation[stream]++;
 		if(grew) *grew = true;
 		VP_CHECK_HIP(hipSetDevice(ctx->device)); // hipMalloc / hipFree act on the current device, which a multi-context caller may have moved
 		VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));

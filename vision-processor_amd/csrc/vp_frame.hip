@@ -6,6 +6,7 @@
 #include "vp_common.h"
 
 #include <cstring>
+#include <vector>
 
 int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, int layout, int qw, int qh, const float* map, int sampler_mode,
 		int fw, int fh, int batch, uint8_t* flat, const VpStrips& strips);
@@ -19,8 +20,103 @@ bool vp_flat_walk_supported(int r, int o);
 int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
 		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed);
 
+static int frame_body(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b);
+
+// ---- vp_ctx_tune "frame_graph": the launches of one frame as a captured hipGraph -----------------------------------------------------------
+// Nothing that changes from one vp_frame call to the next is a kernel argument (the single-pass SAT tells its launches apart by their tickets,
+// vp_sat_tiled.hip sat_launch_state; the list counters clean themselves), so the launch sequence of a (stream, parameters, batch, buffers) tuple is
+// captured the second time it is seen and replayed from then on.  Host-side state the captured launches rely on is re-checked before every
+// replay -- workspace generation (a grown workspace moves), the geometry the stream's coordinate map was built for, the SAT shape the ticket
+// counters were advanced with, the look-back timeout flag, the ticket wrap -- and any mismatch takes the ordinary path, which repairs it.
+static void graph_key(int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b, const VpTuning& tune, std::vector<uint8_t>& key) {
+	key.resize(sizeof(int) * 2 + sizeof(*p) + sizeof(raw) + sizeof(*b) + sizeof(tune));
+	uint8_t* k = key.data();
+	memcpy(k, &stream, sizeof(int)); k += sizeof(int);
+	memcpy(k, &batch, sizeof(int)); k += sizeof(int);
+	memcpy(k, p, sizeof(*p)); k += sizeof(*p);
+	memcpy(k, &raw, sizeof(raw)); k += sizeof(raw);
+	memcpy(k, b, sizeof(*b)); k += sizeof(*b);
+	memcpy(k, &tune, sizeof(tune));
+}
+
+static void graph_drop(VpFrameGraph& g) {
+	if(g.exec) (void)hipGraphExecDestroy(g.exec);
+	if(g.graph) (void)hipGraphDestroy(g.graph);
+	g.exec = nullptr;
+	g.graph = nullptr;
+}
+
+void vp_frame_graphs_clear(VpContext* ctx) {
+	for(VpFrameGraph& g : ctx->graphs) graph_drop(g);
+	ctx->graphs.clear();
+}
+
+static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
+	std::vector<uint8_t> key;
+	graph_key(stream, p, raw, batch, b, ctx->tune, key);
+	VpFrameGraph* g = nullptr;
+	for(VpFrameGraph& c : ctx->graphs)
+		if(c.key == key) g = &c;
+	if(!g) { // first sighting: the ordinary path (sizes the workspaces, builds the coordinate map, resets the SAT state if the shape is new)
+		if(ctx->graphs.size() >= 64) vp_frame_graphs_clear(ctx);
+		ctx->graphs.emplace_back();
+		ctx->graphs.back().key = key;
+		return frame_body(ctx, stream, p, raw, batch, b);
+	}
+	const bool tiled = p->sat_variant == VP_SAT_TILED;
+	int* flag = ctx->host_flag[stream];
+	const bool poisoned = flag && *reinterpret_cast<volatile int*>(flag) != 0;
+	if(g->exec) {
+		const bool near_wrap = tiled && ((uint64_t)ctx->sat_epoch[stream] + 4) * g->sat_tickets >= (uint64_t(1) << 32);
+		if(g->ws_generation == ctx->ws_generation[stream] && memcmp(g->map_key, ctx->map_key[stream], sizeof(g->map_key)) == 0 && (!tiled || (g->sat_shape == ctx->sat_shape[stream] && g->sat_tickets == ctx->sat_tickets[stream])) &&
+				!poisoned && !near_wrap && ctx->sat_epoch[stream] < (1u << 30) - 4) {
+			if(tiled) ++ctx->sat_epoch[stream]; // the replayed SAT launch draws its tickets like any other
+			VP_CHECK_HIP(hipGraphLaunch(g->exec, ctx->streams[stream]));
+			return VP_OK;
+		}
+		graph_drop(*g); // something the captured launches rely on has moved: ordinary path now, capture again next time
+		return frame_body(ctx, stream, p, raw, batch, b);
+	}
+	if(g->failed || poisoned) return frame_body(ctx, stream, p, raw, batch, b);
+	// second sighting: capture.  A reset of the SAT state or a growing workspace inside the capture is refused by those functions (ctx->capturing) and lands here as a failure.
+	hipStream_t s = ctx->streams[stream];
+	if(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+		(void)hipGetLastError();
+		g->failed = true;
+		return frame_body(ctx, stream, p, raw, batch, b);
+	}
+	ctx->capturing[stream] = true;
+	const uint32_t epoch_before = ctx->sat_epoch[stream];
+	const int rc = frame_body(ctx, stream, p, raw, batch, b);
+	ctx->capturing[stream] = false;
+	hipGraph_t graph = nullptr;
+	const hipError_t e = hipStreamEndCapture(s, &graph);
+	if(rc != VP_OK || e != hipSuccess || !graph || hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+		(void)hipGetLastError();
+		if(graph) (void)hipGraphDestroy(graph);
+		g->exec = nullptr;
+		g->failed = true;
+		ctx->sat_epoch[stream] = epoch_before; // nothing was launched
+		return frame_body(ctx, stream, p, raw, batch, b);
+	}
+	g->graph = graph;
+	g->ws_generation = ctx->ws_generation[stream];
+	memcpy(g->map_key, ctx->map_key[stream], sizeof(g->map_key));
+	g->sat_shape = ctx->sat_shape[stream];
+	g->sat_tickets = ctx->sat_tickets[stream];
+	VP_CHECK_HIP(hipGraphLaunch(g->exec, s)); // (the capture counted this launch's SAT tickets already)
+	return VP_OK;
+}
+
 extern "C" int vp_frame(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
 	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(p && raw && b, "vp_frame: null pointer");
+	// stage events are per-launch objects and the debug views are occasional: those calls take the ordinary path
+	if(ctx->tune.frame_graph && !ctx->events_on && !b->planes && !b->graddot && !b->blobcenter && ctx->streams[stream] != nullptr) return frame_graphed(ctx, stream, p, raw, batch, b);
+	return frame_body(ctx, stream, p, raw, batch, b);
+}
+
+static int frame_body(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
 	VP_REQUIRE(p && raw && b, "vp_frame: null pointer");
 	const bool local = p->sat_variant == VP_SAT_LOCAL;
 	VP_REQUIRE(b->flat && (b->sat || local) && b->matches && b->counter, "vp_frame: flat, sat, matches and counter buffers are required");

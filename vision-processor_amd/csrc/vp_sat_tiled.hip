@@ -41,7 +41,8 @@ struct TiledArgs {
 	int w, h, o;
 	int tilesX, tilesY, nTiles, batch;
 	int pitch;      // generic kernel: size of the LDS halo array in dwords
-	uint32_t ticket_base, epoch;
+	uint32_t tickets_per_launch; // tickets every launch takes from each frame's queue: LAUNCH-INVARIANT for a given shape (host: reset when it changes)
+	uint32_t ticket_base, epoch; // NOT launch arguments: derived inside the kernel from the first ticket a workgroup draws (see sat_launch_state)
 	u64 *V, *H, *K; // carry granules: [tile][TW], [tile][TH], [tile]
 	const uint32_t* order; // ticket -> (ti << 16 | tj): anti-diagonal order of the tile grid (a linear extension of the carry dependencies)
 	uint32_t* ctrl; // [0] abort word, [16 + 16 f] ticket counter of frame f (monotonic across launches, one 64-B line each)
@@ -64,6 +65,16 @@ __device__ __forceinline__ void raise_timeout(const TiledArgs& a) {
 }
 __device__ __forceinline__ bool aborted(const TiledArgs& a) {
 	return __hip_atomic_load((gu32*)a.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// Which launch is this?  The per-frame ticket counters are monotonic across launches and every launch of a given shape draws exactly
+// tickets_per_launch tickets from each of them (launches of one stream are ordered), so the first ticket t0 a workgroup draws names its launch:
+// number L = t0 / tickets_per_launch, ticket base L * tickets_per_launch, granule epoch L + 1.  Nothing that changes from launch to launch is a
+// kernel argument: the launch can be captured in a hipGraph and replayed (vp_ctx_tune "frame_graph").
+__device__ __forceinline__ void sat_launch_state(uint32_t t0, uint32_t tickets_per_launch, uint32_t& base, uint32_t& epoch) {
+	const uint32_t L = t0 / tickets_per_launch;
+	base = L * tickets_per_launch;
+	epoch = L + 1u;
 }
 
 // Exclusive carry of this lane's element along one chain: walk the predecessors (nearest first), adding aggregates
@@ -127,7 +138,8 @@ __device__ __forceinline__ bool early_resolve(u64 pre0, u64 pre1, int npred, con
 // 1..4) run k_sat_fast2 below; this is the fallback for offset 0 / > 4 and for the unfused entry point.
 // LDS image of a tile: interior I[rows][64] dwords (rows = TH + 2o) followed by the halo columns Hh[rows][2o].
 template<bool FUSED>
-__global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
+__global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a_in) {
+	TiledArgs a = a_in; // ticket_base and epoch are filled in below
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int o = FUSED ? a.o : 0;
 	const int rows = TH + 2 * o;
@@ -157,10 +169,16 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 	if(loader) {
 		const uint32_t t0 = atomicAdd(queue, 1u);
 		pending = atomicAdd(queue, 1u);
-		misc[0] = (int)(t0 - a.ticket_base);
+		uint32_t base, epoch;
+		sat_launch_state(t0, a.tickets_per_launch, base, epoch);
+		misc[0] = (int)(t0 - base);
+		misc[4] = (int)base;
+		misc[5] = (int)epoch;
 	}
 	__syncthreads();
 	int rem = misc[0];
+	a.ticket_base = (uint32_t)__builtin_amdgcn_readfirstlane(misc[4]);
+	a.epoch = (uint32_t)__builtin_amdgcn_readfirstlane(misc[5]);
 	if(rem < 0 || rem >= perFrame) return; // two tickets taken, none valid: the host accounts for exactly two overshoots
 
 	for(;;) {
@@ -312,7 +330,8 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 // LDS image of a tile: raw[rows][72] dwords = [4 - O pad | O halo | 64 interior | O halo | pad], rows = 64 + 2 O.
 // RAG: width not a multiple of 64 (the last tile column clamps / masks per pixel).  GD: also write the F32 gradDot view.
 template<int O, int WPC, bool GD, bool RAG>
-__global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a) {
+__global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a_in) {
+	TiledArgs a = a_in; // ticket_base and epoch are filled in below
 	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
 	constexpr int ROWS = TH + 2 * O, PITCH = TW + 8;
 	constexpr int NI = (ROWS + 15) / 16;             // interior: 16 lanes x 16 B per row, 16 rows per pass
@@ -338,13 +357,19 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	uint32_t pending = 0;
 	if(loader) {
 		const uint32_t t0 = atomicAdd(queue, 1u);
+		uint32_t base, epoch;
+		sat_launch_state(t0, a.tickets_per_launch, base, epoch);
 		// (with one workgroup per tile a second ticket could only be out of range: not asking for it halves the burst on the
 		// frame's ticket counter, which is what a single-frame launch spends a third of its time on)
-		pending = a.single ? a.ticket_base + (uint32_t)perFrame : atomicAdd(queue, 1u);
-		misc[0] = (int)(t0 - a.ticket_base);
+		pending = a.single ? base + (uint32_t)perFrame : atomicAdd(queue, 1u);
+		misc[0] = (int)(t0 - base);
+		misc[4] = (int)base;
+		misc[5] = (int)epoch;
 	}
 	__syncthreads();
 	int rem = misc[0];
+	a.ticket_base = (uint32_t)__builtin_amdgcn_readfirstlane(misc[4]);
+	a.epoch = (uint32_t)__builtin_amdgcn_readfirstlane(misc[5]);
 	if(rem < 0 || rem >= perFrame) return;
 
 	// buffer descriptors of this frame (host guarantees w * h * 4 < 2^31): 32-bit lane offsets + a scalar tile offset
@@ -657,15 +682,38 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	bool grew = false;
 	VP_TRY(vp_workspace(ctx, stream, 1, bCtl + bOrd + bV + bH + bK, &base, &grew));
 	if(!ctx->host_flag[stream]) {
+		VP_REQUIRE(!ctx->capturing[stream], "first use of the single-pass SAT on this stream inside a graph capture");
 		VP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flag[stream]), 64, hipHostMallocMapped));
 		*ctx->host_flag[stream] = 0;
 	}
 	const bool poisoned = *reinterpret_cast<volatile int*>(ctx->host_flag[stream]) != 0; // an earlier launch timed out (reported by vp_sync)
 	// the per-frame ticket counters advance by tilesX*tilesY per launch: a different tiling or batch restarts the count
-	const uint64_t shape = ((uint64_t)a.tilesX << 40) | ((uint64_t)a.tilesY << 20) | (uint64_t)batch;
-	const bool reshaped = ctx->sat_shape[stream] != shape;
+	// persistent grid: P workgroups per frame queue; every workgroup overshoots its queue by exactly two tickets (one workgroup per tile: one ticket each)
+	const int perFrame = a.tilesX * a.tilesY;
+	// resident workgroups per CU of k_sat_fast2 (vp_ctx_tune; 5 or 6 have their own register budget).  Small launches do better with fewer,
+	// longer-lived workgroups (each tile's prefetch rides on the previous tile): 8 frames 80.0 -> 78.6 us, 32 frames 205 -> 196 us; no effect at 128
+	const int wpc = ctx->tune.sat_workgroups_per_cu > 0 ? ctx->tune.sat_workgroups_per_cu : (batch < 64 ? 4 : 5);
+	// k_sat_fast2 takes any width (the last tile column clamps / masks per pixel); rows need not be 16-byte aligned for buffer accesses
+	const bool aligned16 = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
+			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0);
+	const bool fast = fused && o >= 1 && o <= 4 && ((w % TW) == 0 ? aligned16 : true) && (size_t)w * h * 4 < 0x7fffffffu && (size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu;
+	int P = ((fast ? wpc : 4) * ctx->cu_count + batch - 1) / batch;
+	if(P < 1) P = 1;
+	if(P > perFrame) P = perFrame;
+	a.single = fast && P >= perFrame ? 1 : 0;
+	a.tickets_per_launch = a.single ? (uint32_t)P : (uint32_t)(perFrame + 2 * P);
+	// The kernels tell launches apart by first ticket / tickets_per_launch (sat_launch_state): every launch since the last reset must have drawn
+	// the same number of tickets per frame queue, so a different tiling, batch or grid restarts the count.  The host only keeps count of the
+	// launches to restart before the 32-bit ticket counters (and the 30-bit epochs) wrap.
+	const uint64_t shape = ((uint64_t)a.tilesX << 44) | ((uint64_t)a.tilesY << 24) | (uint64_t)batch;
+	const bool reshaped = ctx->sat_shape[stream] != shape || ctx->sat_tickets[stream] != a.tickets_per_launch;
 	ctx->sat_shape[stream] = shape;
-	const bool reset = grew || poisoned || reshaped || ctx->sat_epoch[stream] >= (1u << 30) - 2;
+	ctx->sat_tickets[stream] = a.tickets_per_launch;
+	const bool reset = grew || poisoned || reshaped || ctx->sat_epoch[stream] >= (1u << 30) - 2 || ((uint64_t)ctx->sat_epoch[stream] + 2) * a.tickets_per_launch >= (uint64_t(1) << 32);
+	if(reset && ctx->capturing[stream]) {
+		vp_set_error("the single-pass SAT state would have to be reset inside a graph capture");
+		return VP_ERR_INVALID;
+	}
 	if(reset) {
 		if(!grew) {
 			VP_CHECK_HIP(hipStreamSynchronize(s));
@@ -673,10 +721,9 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 		}
 		*ctx->host_flag[stream] = 0;
 		ctx->sat_epoch[stream] = 0;
-		ctx->sat_ticket_base[stream] = 0;
 	}
-	a.epoch = ++ctx->sat_epoch[stream];
-	a.ticket_base = ctx->sat_ticket_base[stream];
+	++ctx->sat_epoch[stream]; // launches since the reset (this one included) = the epoch the kernel derives
+	a.epoch = a.ticket_base = 0; // derived in the kernel
 	uint8_t* p = static_cast<uint8_t*>(base);
 	a.ctrl = reinterpret_cast<uint32_t*>(p);
 	a.order = reinterpret_cast<const uint32_t*>(p + bCtl);
@@ -703,20 +750,6 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	a.host_flag = dflag;
 	a.strips = vp_make_strips((fused && strips && vp_strips_supported(w, o)) ? const_cast<uint32_t*>(strips) : nullptr, vp_strips_supported(w, o) ? w : 64, h, o >= 1 ? o : 1);
 
-	// persistent grid: P workgroups per frame queue; every workgroup overshoots its queue by exactly two tickets
-	const int perFrame = a.tilesX * a.tilesY;
-	// resident workgroups per CU of k_sat_fast2 (vp_ctx_tune; 5 or 6 have their own register budget).  Small launches do better with fewer,
-	// longer-lived workgroups (each tile's prefetch rides on the previous tile): 8 frames 80.0 -> 78.6 us, 32 frames 205 -> 196 us; no effect at 128
-	const int wpc = ctx->tune.sat_workgroups_per_cu > 0 ? ctx->tune.sat_workgroups_per_cu : (batch < 64 ? 4 : 5);
-	// k_sat_fast2 takes any width (the last tile column clamps / masks per pixel); rows need not be 16-byte aligned for buffer accesses
-	const bool aligned16 = (w & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(sat) & 15) == 0 &&
-			(!graddot_out || (reinterpret_cast<uintptr_t>(graddot_out) & 15) == 0);
-	const bool fast = fused && o >= 1 && o <= 4 && ((w % TW) == 0 ? aligned16 : true) && (size_t)w * h * 4 < 0x7fffffffu && (size_t)2 * a.tilesX * h * o * 4 < 0x7fffffffu;
-	int P = ((fast ? wpc : 4) * ctx->cu_count + batch - 1) / batch;
-	if(P < 1) P = 1;
-	if(P > perFrame) P = perFrame;
-	a.single = fast && P >= perFrame ? 1 : 0;
-	ctx->sat_ticket_base[stream] += a.single ? (uint32_t)P : (uint32_t)(perFrame + 2 * P);
 	const unsigned grid = (unsigned)P * (unsigned)batch;
 	if(fast) {
 		const size_t lds2 = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + 32 * TW + TH + TW + TH + 8);
