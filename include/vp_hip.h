@@ -12,6 +12,12 @@
  * vp_last_error() (thread-local).  The C++ facade above this ABI turns any non-zero status into the reference's
  * FATAL() behaviour (log.h:21: stderr + exit(1)).
  *
+ * Threads: a context is thread-COMPATIBLE, not thread-safe -- launches, tuning and synchronisation of one VpContext come from one thread at a
+ * time (the reference launches from its main thread only); different contexts may be driven by different threads at once
+ * (host/feeds_multi.cpp: one per device).  The exceptions are the blocking map / unmap helpers of VpBuffer / VpImage and vp_image_acquire /
+ * vp_image_release, which other threads may call while the owner launches (the reference's RTP and snapshot threads do, rtpstreamer.cpp:177-181,
+ * snapshotwriter.cpp:52-54).
+ *
  * The library fails loudly when no HIP device is usable; there is no CPU fallback of any kind.
  */
 #ifndef VP_HIP_H
@@ -226,8 +232,9 @@ int vp_blobcenter_list(VpContext* ctx, int stream, const uint8_t* flat, const in
 		int circle_radius, float circ_threshold, float min_score, int list_radius, int max_matches, int order,
 		VpMatch* matches, uint32_t* idx, int32_t* counter, float* blobcenter_out);
 
-/* gradient_dotproduct + sat_horizontal/vertical + circle + matches in one kernel, no global table (VP_SAT_LOCAL).  Supported for the
- * (circle_radius, grad_offset) pairs a geometry can form with circle radius 2..12; other pairs return VP_ERR_INVALID. */
+/* gradient_dotproduct + sat_horizontal/vertical + circle + matches in one kernel, no global table (VP_SAT_LOCAL), for the (circle_radius,
+ * grad_offset) pairs a geometry can form with circle radius 2..12; any other pair gives the same list through a table private to the library
+ * (single-pass SAT into a workspace, then the fused circle + matches): never refused, merely no faster than VP_SAT_TILED. */
 int vp_flat_bloblist(VpContext* ctx, int stream, const uint8_t* flat, int w, int h, int batch, int grad_offset, int circle_radius, float circ_threshold, float min_score,
 		int list_radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter);
 

@@ -390,13 +390,13 @@ def test_local_table_variant_on_the_goldens(env, cfg, mode, seed):
 
 @pytest.mark.parametrize("name", sorted(cases.flat_cases()))
 def test_local_table_variant_on_the_flat_edge_cases(env, name):
-    """The hand-made flat images (blobs on every border, plateaus, uniform discs with infinite score, list overflow, the 2^24-guard violation)
-    through vp_flat_bloblist, where the (r, o) pair has a kernel."""
+    """The hand-made flat images (blobs on every border, plateaus, uniform discs with infinite score, list overflow, the 2^24-guard violation, o = 0)
+    through vp_flat_bloblist: the walker where the (r, o) pair has one, the private-table route otherwise -- never refused."""
     capi, torch = env
     case = cases.flat_cases()[name]
     g = cases.load_golden(name)
-    if "blobcenter" in case or case["o"] < 1:
-        pytest.skip("case starts from a hand-made blobCenter image / o = 0: no gradientDot to form")
+    if "blobcenter" in case:
+        pytest.skip("case starts from a hand-made blobCenter image")
     ctx = capi.Context(0, n_streams=1)
     try:
         flat = case["flat"]
@@ -405,11 +405,8 @@ def test_local_table_variant_on_the_flat_edge_cases(env, name):
         m = torch.zeros(mm * 22, dtype=torch.uint8, device="cuda")
         idx = torch.zeros(mm, dtype=torch.int32, device="cuda")
         cnt = torch.full((3,), -9, dtype=torch.int32, device="cuda")
-        try:
-            ctx.flat_bloblist(dev(torch, flat), w, h, 1, case["o"], case["r"], case["thr"], case["min_score"], case["R"], mm, capi.ORDER_RASTER, m, idx, cnt)
-        except capi.VpError as e:
-            assert e.code == -1 and "no kernel for circle radius" in str(e)  # a hand-made (r, o) pair no geometry forms: refused loudly
-            pytest.skip(str(e))
+        # (r, o) pairs no geometry forms (r = 6 with o = 1, o = 0, ...) have no walker: the same list through the library's private table
+        ctx.flat_bloblist(dev(torch, flat), w, h, 1, case["o"], case["r"], case["thr"], case["min_score"], case["R"], mm, capi.ORDER_RASTER, m, idx, cnt)
         ctx.sync()
         c = cnt.cpu().numpy()
         assert np.array_equal(c, g["counter"]), (c, g["counter"])

@@ -388,3 +388,41 @@ def test_frame_graph_replay_is_result_neutral(env, port, variant):
                     assert np.array_equal(b["idx"][k].cpu().numpy().view(np.uint32)[:n], w_["idx"]) and b["m"][k].cpu().numpy()[:22 * n].tobytes() == w_["m"].tobytes(), (rnd, s, k)
     finally:
         ctx.close()
+
+
+def test_local_variant_never_refuses_a_geometry(env, port):
+    """VP_SAT_LOCAL for a (circle radius, gradient offset) pair without a walker (fieldScale 1.5 mm / px: r = 14, o = 5) and, beside it, one with
+    (3.4 mm / px: r = 6, o = 2): vp_frame returns the oracle's list either way -- the first through the library's private table -- exactly as
+    VP_SAT_TILED does for the same frames."""
+    capi, torch = env
+    base = cfgs.T_MID
+    for fs, thr in ((1.5, 15.0), (3.4, 15.0)):
+        cfg = base.with_(name=f"t_mid_fs{fs}", field_scale=fs, off_x=-320.0 * fs, off_y=-192.0 * fs, visible_len=640.0 * fs * 1.05, circ_threshold=thr)
+        B, mm = 2, cfg.max_matches
+        raws = np.stack([cfg.synth(40 + i) for i in range(B)])
+        model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+        ctx = capi.Context(0, n_streams=1)
+        try:
+            d_raw = dev(torch, raws)
+            out = {}
+            for variant in (capi.SAT_LOCAL, capi.SAT_TILED):
+                p = capi.frame_params(cfg, sat_variant=variant, order=capi.ORDER_RASTER)
+                flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+                sat = torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda") if variant == capi.SAT_TILED else None
+                m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"); idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+                cnt = torch.full((B, 3), -9, dtype=torch.int32, device="cuda")
+                for _ in range(2):
+                    ctx.frame(p, d_raw, B, flat, sat, m, cnt, idx=idx)
+                ctx.sync()
+                out[variant] = (flat.cpu().numpy(), m.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy())
+            for k in range(B):
+                wm, widx, wcnt = port.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                            cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+                for variant in (capi.SAT_LOCAL, capi.SAT_TILED):
+                    flat, m, idx, cnt = out[variant]
+                    assert np.array_equal(cnt[k], wcnt), (fs, variant, cnt[k], wcnt)
+                    n = min(int(wcnt[0]), mm)
+                    assert np.array_equal(idx[k].view(np.uint32)[:n], widx) and m[k, :22 * n].tobytes() == wm.tobytes(), (fs, variant, k)
+            assert cfg.circle_radius == (14 if fs == 1.5 else 6)
+        finally:
+            ctx.close()

@@ -13,6 +13,7 @@
 #include "vp_hip.h"
 
 #define VP_MAX_STREAMS 16
+#define VP_WS_SLOTS 6
 
 struct VpEventRec {
 	const char* stage;
@@ -69,7 +70,7 @@ struct VpContext {
 	int n_streams = 0;
 	bool own_streams = true;
 	hipStream_t streams[VP_MAX_STREAMS] = {};
-	VpWorkspace ws[5][VP_MAX_STREAMS];   // slot 0: per-call scratch (candidate lists, append-order records); slot 1: persistent SAT tile carries; slot 2: coordinate map; slot 3: halo strips;
+	VpWorkspace ws[VP_WS_SLOTS][VP_MAX_STREAMS]; // slot 5: private table of VP_SAT_LOCAL calls whose (radius, offset) pair has no walker; slot 0: per-call scratch (candidate lists, append-order records); slot 1: persistent SAT tile carries; slot 2: coordinate map; slot 3: halo strips;
 	                                     // slot 4: self-cleaning counters of the blob list (zero between launches: nothing else may ever be placed there)
 	unsigned char map_key[VP_MAX_STREAMS][96] = {}; // geometry the cached coordinate map of each stream was built for
 	uint32_t sat_epoch[VP_MAX_STREAMS] = {};       // single-pass SAT launches on this stream since its carry state was last reset (the kernels derive the same number from their tickets)

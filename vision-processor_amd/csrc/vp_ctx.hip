@@ -82,7 +82,7 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 	(void)hipSetDevice(ctx->device);
 	for(int i = 0; i < ctx->n_streams; i++) {
 		(void)hipStreamSynchronize(ctx->streams[i]);
-		for(int k = 0; k < 5; k++)
+		for(int k = 0; k < VP_WS_SLOTS; k++)
 			if(ctx->ws[k][i].ptr) (void)hipFree(ctx->ws[k][i].ptr);
 		if(ctx->host_flag[i]) (void)hipHostFree(ctx->host_flag[i]);
 		if(ctx->own_streams) (void)hipStreamDestroy(ctx->streams[i]);

@@ -129,7 +129,6 @@ static int frame_body(VpContext* ctx, int stream, const VpFrameParams* p, const 
 	VP_REQUIRE(p->sat_variant >= VP_SAT_TILED && p->sat_variant <= VP_SAT_LOCAL, "vp_frame: bad SAT variant %d", p->sat_variant);
 	VP_REQUIRE(p->order == VP_ORDER_ATOMIC || p->order == VP_ORDER_RASTER, "vp_frame: bad order");
 	VP_REQUIRE((reinterpret_cast<uintptr_t>(b->matches) & 1) == 0, "vp_frame: matches must be 2-byte aligned");
-	VP_REQUIRE(!local || vp_flat_walk_supported(p->circle_radius, p->grad_offset), "vp_frame: VP_SAT_LOCAL has no kernel for circle radius %d with gradient offset %d", p->circle_radius, p->grad_offset);
 	// the workspaces below are allocated on the CURRENT device: a caller driving several contexts from one thread (host/feeds_multi.cpp) must land on ours
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	// halo strips for the single-pass SAT: written by whichever resampling kernel produces flat (6 % of flat, saves the SAT

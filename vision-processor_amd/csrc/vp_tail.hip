@@ -655,6 +655,11 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 }
 
 // flat -> blob list with no global table (VP_SAT_LOCAL).  (r, o) pairs: every pair ceil(20 / fs), ceil(25 / fs) / 3 can form for r = 2 .. 12.
+int vp_sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w, int h, int offset, int batch, int variant, int32_t* sat, float* gd, const char* name, const uint32_t* strips,
+		int32_t* zero3, bool* zeroed); // vp_sat.hip
+int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
+		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed);
+
 // the (circle radius, gradient offset) pairs k_flat_walk is instantiated for (the VP_FW list below)
 bool vp_flat_walk_supported(int r, int o) {
 	static const int pairs[][2] = {{2, 1}, {3, 1}, {4, 1}, {5, 2}, {6, 2}, {7, 2}, {7, 3}, {8, 3}, {9, 3}, {9, 4}, {10, 4}, {11, 4}, {12, 4}};
@@ -668,9 +673,19 @@ int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w
 	hipStream_t s = ctx->streams[stream];
 	// every argument is checked before anything is enqueued: a refused call leaves the caller's counters and records untouched
 	VP_REQUIRE((size_t)w * h * 4 < 0x7fffffffu, "VP_SAT_LOCAL: frame too large");
-	VP_REQUIRE(vp_flat_walk_supported(circle_radius, grad_offset), "VP_SAT_LOCAL: no kernel for circle radius %d with gradient offset %d (the pairs real geometries form are built: r 2..12 with o = ceil(25 / fs) / 3)", circle_radius, grad_offset);
+	if(!vp_flat_walk_supported(circle_radius, grad_offset)) {
+		// A (radius, offset) pair without a walker (the pairs real geometries form with r = 2..12 are built; r > 12 needs fieldScale < 1.67 mm per
+		// pixel): the same list through a PRIVATE table -- the single-pass SAT into a workspace, then circle + blobList from it.  VP_SAT_LOCAL
+		// never refuses a geometry; it is merely no faster than VP_SAT_TILED for these.
+		VP_REQUIRE(circle_radius >= 0 && grad_offset >= 0 && grad_offset <= 32, "VP_SAT_LOCAL: circle radius %d / gradient offset %d out of range", circle_radius, grad_offset);
+		void* table = nullptr;
+		VP_TRY(vp_workspace(ctx, stream, 5, sizeof(int32_t) * (size_t)w * h * batch, &table));
+		bool zeroed = false;
+		VP_TRY(vp_sat_common(ctx, stream, flat, true, w, h, grad_offset, batch, VP_SAT_TILED, static_cast<int32_t*>(table), nullptr, "gradientDot+sat (private table)", nullptr, counter, &zeroed));
+		return vp_list_from_blobcenter(ctx, stream, flat, nullptr, static_cast<const int32_t*>(table), circle_radius, nullptr, w, h, batch, thr, min_score, radius, max_matches, order, matches, idx,
+				counter, zeroed);
+	}
 	const int use = 63 - 2 * (circle_radius + grad_offset);
-	VP_REQUIRE(use >= 16, "VP_SAT_LOCAL: circle radius %d + gradient offset %d too large for a wavefront strip", circle_radius, grad_offset);
 	ListScratch ws;
 	VP_TRY(list_scratch(ctx, stream, batch, max_matches, &ws));
 	k_zero<<<vp_div_up(3 * batch, 256), 256, 0, s>>>(counter, 3 * batch); // main.cpp:283-288
@@ -703,7 +718,7 @@ int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w
 	}
 	VP_FW(2, 1) VP_FW(3, 1) VP_FW(4, 1) VP_FW(5, 2) VP_FW(6, 2) VP_FW(7, 2) VP_FW(7, 3) VP_FW(8, 3) VP_FW(9, 3) VP_FW(9, 4) VP_FW(10, 4) VP_FW(11, 4) VP_FW(12, 4)
 #undef VP_FW
-	VP_REQUIRE(launched, "VP_SAT_LOCAL: no kernel for circle radius %d with gradient offset %d (the pairs real geometries form are built: r 2..12 with o = ceil(25 / fs) / 3)", circle_radius, grad_offset);
+	VP_REQUIRE(launched, "VP_SAT_LOCAL: vp_flat_walk_supported() and the kernel list disagree on (%d, %d)", circle_radius, grad_offset);
 	return vp_launch_ok("gradientDot+circle+blobList (local table)");
 }
 
