@@ -140,3 +140,17 @@ def test_struct_layouts_match_the_reference():
     assert C.sizeof(cases.vp.hostlib.VpCameraModel) == 72  # Perspective.h:22-29
     assert capi.MATCH_DTYPE.itemsize == 22                 # main.cpp:33-41
     assert [capi.MATCH_DTYPE.fields[k][1] for k in ("x", "y", "color", "center", "circ", "score")] == [0, 4, 8, 11, 14, 18]
+
+
+def test_bench_rank_launcher_stops_all_ranks_when_one_dies():
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself and polls them all: here (no GPU) every rank fails its first check,
+    and the parent must come back at once with a non-zero exit code and that rank's stderr -- not sit in a rendezvous until a collective times out."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher's failure path")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert "exited with code" in out.stderr and "the other ranks were stopped" in out.stderr and "needs a GPU" in out.stderr
+    assert not any(line.startswith("{") for line in out.stdout.splitlines())  # no bench line on a failed run

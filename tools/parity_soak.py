@@ -13,6 +13,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 O.build(ref=False)
 port = O.Port(threads=8)
 ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+gctx = capi.Context(0, n_streams=2)  # library-owned streams with vp_ctx_tune "frame_graph": ordinary call, capture, replay of the same call
+gctx.tune("frame_graph", 1)
 rng = np.random.default_rng(2024)
 pool = [cfgs.T_MID, cfgs.T_RGGB, cfgs.T_GRBG, cfgs.T_BGR, cfgs.T_RAGGED, cfgs.T_RAGGED.with_(name="t_ragged_even", qw=68, qh=46), cfgs.CFG1]
 t0, frames, launches, seed = time.time(), 0, 0, 10_000
@@ -27,6 +29,7 @@ while time.time() - t0 < budget:
     order = capi.ORDER_RASTER if rng.integers(2) else capi.ORDER_ATOMIC
     variant = [capi.SAT_TILED, capi.SAT_TILED, capi.SAT_LOCAL, capi.SAT_LOCAL, capi.SAT_TWOPASS][int(rng.integers(5))]
     ctx.tune("tail_segment_rows", int(rng.choice([0, 0, 16, 32, 128])))
+    ctx.tune("sat_workgroups_per_cu", int(rng.choice([0, 0, 2, 3, 6])))
     mm = cfg.max_matches
     raws = [cfg.synth(seed + i) for i in range(B)]
     seed += B
@@ -40,6 +43,18 @@ while time.time() - t0 < budget:
     ctx.frame(p, d_raw, B, flat, sat, matches, counter, idx=idx)
     ctx.sync()
     launches += 1
+    if rng.integers(3) == 0:  # the same call three times through the graph path on a library stream: the replay must leave the same bytes
+        st = int(rng.integers(2))
+        g = dict(flat=torch.zeros_like(flat), sat=torch.zeros_like(sat) if sat is not None else None, m=torch.zeros_like(matches), i=torch.zeros_like(idx), c=torch.zeros_like(counter))
+        for rep in range(3):
+            gctx.frame(p, d_raw, B, g["flat"], g["sat"], g["m"], g["c"], idx=g["i"], stream=st)
+        gctx.sync()
+        launches += 3
+        assert torch.equal(g["flat"], flat) and (sat is None or torch.equal(g["sat"], sat)) and torch.equal(g["c"], counter), "graph replay differs (flat / SAT / counters)"
+        if order == capi.ORDER_RASTER:
+            for i in range(B):
+                n = min(int(counter[i, 0]), mm)
+                assert torch.equal(g["i"][i, :n], idx[i, :n]) and torch.equal(g["m"][i, :22 * n], matches[i, :22 * n]), "graph replay differs (records)"
     hf, hs, hm, hi, hc = flat.cpu().numpy(), (sat.cpu().numpy() if sat is not None else None), matches.cpu().numpy(), idx.cpu().numpy().view(np.uint32), counter.cpu().numpy()
     model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
     for i in range(B):

@@ -1,6 +1,6 @@
 // vp_feeds: `feeds` independent camera feeds through the whole chain on one GPU, in C++ on the C ABI alone (no Python, no PyTorch):
-//   vp_frame (one launch group per step) -> read-back of counters + blob records -> per feed: hypotheses, SSL_DetectionFrame,
-//   tracker, SSL_WrapperPacket (vph_detect_batch on host threads), the CPU stage of step k running while the GPU works on step k + 1.
+//   vp_frame (one launch group per step) -> vp_records_compact -> read-back of the compact slots -> per feed: hypotheses, SSL_DetectionFrame,
+//   tracker, SSL_WrapperPacket (vph_detect_batch_slots on host threads), the CPU stage of step k running while the GPU works on step k + 1.
 // This is the loop of src/main.cpp:262-372 for many cameras at once: what a deployment that puts several cameras on one MI355X runs.
 //
 // usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1]
@@ -122,13 +122,17 @@ int main(int argc, char** argv) {
 	// two sets of per-step buffers: step k runs on stream k & 1 while the host reads step k - 1 back from the other set
 	VpFrameBuffers buf[2];
 	VpFrameSlab* slab[2];
-	void* hMatches[2];
-	void* hCounter[2];
-	const size_t matchBytes = sizeof(VpMatch) * (size_t)maxBlobs * feeds, counterBytes = sizeof(int32_t) * 3 * (size_t)feeds;
+	// what the host reads back per step is the compact form: counter[3], n and the n records of each feed (main.cpp:299-301), not the
+	// fixed-capacity arrays (0.64 MB instead of 5.6 MB at 128 feeds)
+	const int cap = 192, packetSlot = 4096;
+	size_t slotBytes = 0;
+	const size_t compactBytes = vp_record_layout_compact(feeds, cap, &slotBytes, nullptr, nullptr);
+	uint8_t* dSlots[2];
+	void* hSlots[2];
 	for(int s = 0; s < 2; s++) {
 		CK(vp_frame_buffers_create(ctx, &p, feeds, 0, &buf[s], &slab[s])); // allocated once, the table and flat from placement-checked blocks
-		CK(vp_malloc_host(ctx, matchBytes, &hMatches[s]));
-		CK(vp_malloc_host(ctx, counterBytes, &hCounter[s]));
+		CK(vp_malloc_device(ctx, compactBytes, (void**)&dSlots[s]));
+		CK(vp_malloc_host(ctx, compactBytes, &hSlots[s]));
 	}
 	// one detector per feed: own colour model, own tracker (main.cpp runs one process per camera)
 	std::vector<VphDetector*> detectors;
@@ -146,9 +150,7 @@ int main(int argc, char** argv) {
 			}
 			detectors.push_back(d);
 		}
-	const int packetCap = 4092;
-	std::vector<uint8_t> packets((size_t)feeds * packetCap);
-	std::vector<int32_t> lengths(feeds);
+	std::vector<uint8_t> packets((size_t)feeds * packetSlot); // one slot per feed: [int32 length | SSL_WrapperPacket]
 
 	long blobs = 0, packetBytes = 0;
 	double waitMs = 0, stageMs = 0, launchMs = 0;
@@ -159,21 +161,31 @@ int main(int argc, char** argv) {
 		CK(vp_sync(ctx, s));
 		const auto w1 = now();
 		waitMs += ms(w0, w1);
-		const int32_t* c = static_cast<const int32_t*>(hCounter[s]);
-		for(int i = 0; i < feeds; i++) blobs += c[3 * i] < maxBlobs ? c[3 * i] : maxBlobs;
+		const uint8_t* slots = static_cast<const uint8_t*>(hSlots[s]);
+		for(int i = 0; i < feeds; i++) {
+			int32_t head[4]; // counter[3], n
+			memcpy(head, slots + (size_t)i * slotBytes, sizeof(head));
+			blobs += head[3];
+		}
 		if(!detect) return;
 		const double t = frameNo / 70.0;
-		CK(vph_detect_batch(detectors.data(), feeds, static_cast<const VpMatch*>(hMatches[s]), c, maxBlobs, (uint32_t)frameNo, t, t, t + 0.002, threads, packets.data(), packetCap,
-				lengths.data()));
-		for(int i = 0; i < feeds; i++) packetBytes += lengths[i] > 0 ? lengths[i] : 0;
+		if(vph_detect_batch_slots(detectors.data(), feeds, slots, slotBytes, maxBlobs, (uint32_t)frameNo, t, t, t + 0.002, threads, packets.data(), packetSlot) != VP_OK) {
+			fprintf(stderr, "[FATAL] the CPU stage refused the record slots (a frame has more than %d blobs?)\n", cap);
+			exit(1);
+		}
+		for(int i = 0; i < feeds; i++) {
+			int32_t len;
+			memcpy(&len, packets.data() + (size_t)i * packetSlot, 4);
+			packetBytes += len > 0 ? len : 0;
+		}
 		stageMs += ms(w1, now());
 	};
 	auto launch = [&](int k) {
 		const auto l0 = now();
 		const int s = k & 1;
 		CK(vp_frame(ctx, s, &p, dRaw, feeds, &buf[s]));
-		CK(vp_copy_d2h(ctx, s, hCounter[s], buf[s].counter, counterBytes));
-		CK(vp_copy_d2h(ctx, s, hMatches[s], buf[s].matches, matchBytes));
+		CK(vp_records_compact(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, dSlots[s]));
+		CK(vp_copy_d2h(ctx, s, hSlots[s], dSlots[s], compactBytes));
 		launchMs += ms(l0, now());
 	};
 
@@ -213,8 +225,8 @@ int main(int argc, char** argv) {
 	for(VphDetector* d : detectors) vph_detector_destroy(d);
 	for(int s = 0; s < 2; s++) {
 		vp_frame_buffers_destroy(ctx, slab[s]);
-		vp_free_host(ctx, hMatches[s]);
-		vp_free_host(ctx, hCounter[s]);
+		vp_free_device(ctx, dSlots[s]);
+		vp_free_host(ctx, hSlots[s]);
 	}
 	vp_free_device(ctx, dRaw);
 	vp_ctx_destroy(ctx);
