@@ -492,11 +492,12 @@ def main():
         ctx.tune("placement_candidates", 0)
     slab = ctx.frame_slab(params, B)
     flat, sat, matches, idx, counter = slab.torch_views()
-    # one fixed-size detection record per frame: [counter 3 x i32 | pad 4 | matches mm x 22 | idx mm x u32]
-    rec_bytes = feeds.record_bytes(mm)
-    record = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)]  # double-buffered: the gather of step k overlaps step k+1
-    # vp_frame wants separate dense arrays; the record tensor is filled by three strided device copies per step
-    gathered = [torch.empty((world, B, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if dist else None
+    # what a rank contributes to the per-step gather: the COMPACT records (vp_records_compact: per frame counter[3], n and the n records a host loop
+    # reads, main.cpp:299-301) -- 0.85 MB per rank and step instead of the 6.7 MB of the fixed-capacity arrays
+    cap = feeds.COMPACT_CAP
+    rec_bytes = feeds.compact_block_bytes(B, cap)
+    record = [torch.zeros(rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]  # double-buffered: the gather of step k overlaps step k+1
+    gathered = [torch.empty((world, rec_bytes), dtype=torch.uint8, device="cuda") for _ in range(2)] if dist else None
     pending = [None, None]
     step_no = [0]
 
@@ -557,7 +558,7 @@ def main():
             step_no[0] += 1
             if pending[s] is not None:
                 pending[s].wait()  # the gather issued two steps ago has released record[s] / gathered[s]
-            feeds.pack_records(counter, matches, idx, record[s])
+            ctx.records_compact(counter, matches, idx, B, mm, cap, record[s])
             pending[s] = feeds.gather_records(record[s], gathered[s], dist, async_op=True)
 
     def drain():
@@ -641,6 +642,13 @@ def main():
         per_px = {"raw2quad+resampling": 4.0 + cfg.qw * cfg.qh * (3.0 if cfg.layout == vp.configs.BGR else 4.0) / cfg.n_flat, "gradientDot+sat": 8.0, "satBlobCenter+blobList": 4.0,
                   "gradientDot+satBlobCenter+blobList (local)": 4.0}
         out["stage_roofline_frac"] = {k: round(per_px[k] * cfg.n_flat * B / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in stage_ms.items() if k in per_px}
+        if dist and det is None:
+            # what the last step gathered: rank 0's own slots must be what vp_frame left in its arrays, and no slot may have been too small
+            gc, gn, gm, gi = feeds.unpack_compact(gathered[(step_no[0] - 1) & 1], B, cap)
+            assert np.array_equal(gc[rank].numpy(), cnt_now), "gathered counters differ from this rank's own"
+            assert np.array_equal(gn.numpy(), np.minimum(gc[:, :, 0].numpy(), mm)), f"a frame has more than {cap} blobs: raise feeds.COMPACT_CAP"
+            assert np.array_equal(gi[rank][0].numpy(), idx[0, :int(gn[rank, 0])].cpu().numpy())
+            out["gather"] = {"bytes_per_rank_and_step": rec_bytes, "full_record_bytes": B * feeds.record_bytes(mm), "form": f"compact records, {cap} per frame slot"}
         if det is not None:
             # what the last step emitted: parse this rank's packets back (and, for N > 1, check that the gather delivered every rank's)
             torch.cuda.synchronize()

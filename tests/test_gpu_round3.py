@@ -426,3 +426,47 @@ def test_local_variant_never_refuses_a_geometry(env, port):
             assert cfg.circle_radius == (14 if fs == 1.5 else 6)
         finally:
             ctx.close()
+
+
+def test_records_compact_is_what_the_host_loop_reads(env):
+    """vp_records_compact: per frame counter[3], n = min(counter[0], max_matches, cap) and exactly those n records + pixel indices (main.cpp:299-301),
+    against the host restatement of the slot layout (feeds.pack_compact_host); a slot too small for its frame says so (n < min(counter[0], max));
+    idx may be NULL."""
+    capi, torch = env
+    f = cases.vp.feeds
+    cfg = cfgs.T_MID
+    B, mm = 5, cfg.max_matches
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        raws = dev(torch, np.stack([cfg.synth(600 + i) for i in range(B)]))
+        p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
+        slab = ctx.frame_slab(p, B)
+        ctx.frame_buffers(p, raws, B, slab.b)
+        flat, sat, m, idx, cnt = slab.torch_views()
+        for cap in (256, 30, 7):
+            total, slot, off_m, off_i = ctx.record_layout_compact(B, cap)
+            assert total == f.compact_block_bytes(B, cap) and slot == f.compact_slot_bytes(cap) and off_m == 16
+            out = torch.full((total,), 0xAB, dtype=torch.uint8, device="cuda")
+            ctx.records_compact(cnt, m, idx, B, mm, cap, out)
+            ctx.sync()
+            got = out.cpu()
+            want = f.pack_compact_host(cnt.cpu(), m.cpu(), idx.cpu(), cap)
+            gc, gn, gm, gi = f.unpack_compact(got[None], B, cap)
+            wc, wn, wm, wi = f.unpack_compact(want[None], B, cap)
+            assert torch.equal(gc, wc) and torch.equal(gn, wn)
+            assert int(gn.max()) == min(cap, int(cnt[:, 0].max())) and (cap >= 256) == bool((gn[0] == cnt[:, 0].cpu().clamp(max=mm)).all())
+            for k in range(B):
+                assert torch.equal(gm[0][k], wm[0][k]) and torch.equal(gi[0][k], wi[0][k]), (cap, k)
+            # without indices: the record part is the same, the index part is left alone
+            out2 = torch.full((total,), 0xAB, dtype=torch.uint8, device="cuda")
+            ctx.records_compact(cnt, m, None, B, mm, cap, out2)
+            ctx.sync()
+            g2 = out2.cpu()
+            for k in range(B):
+                n = int(gn[0, k])
+                assert torch.equal(g2[k * slot:k * slot + 16 + 22 * n], got[k * slot:k * slot + 16 + 22 * n])
+                assert bool((g2[k * slot + off_i:k * slot + off_i + 4 * cap] == 0xAB).all())
+        del flat, sat, m, idx, cnt
+        slab.destroy()
+    finally:
+        ctx.close()

@@ -64,6 +64,19 @@ def _worker(rank, world, port, batch, out_dir):
     for r in range(world):
         c, m, i = _detections(r, batch, cfg, mm)
         ok &= np.array_equal(gc[r].numpy(), c) and np.array_equal(gm[r].numpy(), m) and np.array_equal(gi[r].numpy(), i)
+    # the compact form bench.py gathers (vp_records_compact on the device; here its host restatement): one flat block per rank
+    cap = 40
+    block = f.pack_compact_host(torch.from_numpy(counter), torch.from_numpy(matches), torch.from_numpy(idx), cap)
+    assert block.numel() == f.compact_block_bytes(batch, cap) and block.numel() % 256 == 0
+    gblock = torch.zeros((world, block.numel()), dtype=torch.uint8)
+    f.gather_records(block, gblock, dist)
+    cc, cn, cm, ci = f.unpack_compact(gblock, batch, cap)
+    for r in range(world):
+        c, m, i = _detections(r, batch, cfg, mm)
+        ok &= np.array_equal(cc[r].numpy(), c)
+        for b in range(batch):
+            n = min(int(c[b, 0]), mm, cap)
+            ok &= int(cn[r, b]) == n and cm[r][b].numpy().tobytes() == m[b, :22 * n].tobytes() and np.array_equal(ci[r][b].numpy(), i[b, :n])
     # the overlapped form bench.py uses: double-buffered records, async gathers, wait before a buffer is reused
     recs = [torch.zeros_like(record) for _ in range(2)]
     gath = [torch.zeros_like(gathered) for _ in range(2)]

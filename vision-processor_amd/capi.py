@@ -270,6 +270,16 @@ class Context:
     def circularize(self, graddot, w, h, batch, min_r, max_r, out, stream=0):
         self._ck(self.l.vp_circularize(self.h, stream, _ptr(graddot), int(w), int(h), int(batch), int(min_r), int(max_r), _ptr(out)))
 
+    def record_layout_compact(self, batch, cap):
+        self.l.vp_record_layout_compact.restype = C.c_size_t
+        slot, om, oi = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        total = int(self.l.vp_record_layout_compact(int(batch), int(cap), C.byref(slot), C.byref(om), C.byref(oi)))
+        return total, int(slot.value), int(om.value), int(oi.value)
+
+    def records_compact(self, counter, matches, idx, batch, max_matches, cap, out, stream=0):
+        """vp_records_compact: counter[3], n and the n records of every frame into one slot per frame (what a host loop reads back / a gather carries)."""
+        self._ck(self.l.vp_records_compact(self.h, stream, _ptr(counter), _ptr(matches), _ptr(idx), int(batch), int(max_matches), int(cap), _ptr(out)))
+
     def frame_slab(self, params: VpFrameParams, batch, views=0) -> "FrameSlab":
         return FrameSlab(self, params, batch, views)
 

@@ -44,11 +44,60 @@ def unpack_records(gathered: torch.Tensor, max_matches: int):
     return counter, matches, idx
 
 
+# ---- compact records: what vp_records_compact (include/vp_hip.h) leaves per feed -- counter[3], n and the n records the host loop reads -------------
+COMPACT_CAP = 256  # records per slot in bench.py (the synthetic scenes give ~130; the list capacity max_matches stays 2000)
+
+
+def compact_slot_bytes(cap: int = COMPACT_CAP) -> int:
+    """vp_record_layout_compact: [counter 3 x i32 | n i32 | cap x 22 B | pad to 4 | cap x u32], padded to 16 bytes."""
+    m = (16 + MATCH_BYTES * cap + 3) & ~3
+    return (m + 4 * cap + 15) & ~15
+
+
+def compact_block_bytes(batch: int, cap: int = COMPACT_CAP) -> int:
+    return (compact_slot_bytes(cap) * batch + 255) & ~255
+
+
+def pack_compact_host(counter: torch.Tensor, matches: torch.Tensor, idx: torch.Tensor, cap: int = COMPACT_CAP) -> torch.Tensor:
+    """Host restatement of vp_records_compact (CPU tensors; tests and the unpacker's inverse): counter (B,3) int32, matches (B, 22*max) uint8,
+    idx (B, max) int32 -> one block (compact_block_bytes,) uint8.  Bytes of a slot beyond its n records stay zero here (the device leaves them as they were)."""
+    b, mm = counter.shape[0], idx.shape[1]
+    slot = compact_slot_bytes(cap)
+    off_idx = (16 + MATCH_BYTES * cap + 3) & ~3
+    out = torch.zeros(compact_block_bytes(b, cap), dtype=torch.uint8)
+    for f in range(b):
+        n = max(0, min(int(counter[f, 0]), mm, cap))
+        base = f * slot
+        head = torch.tensor([int(counter[f, 0]), int(counter[f, 1]), int(counter[f, 2]), n], dtype=torch.int32)
+        out[base:base + 16] = head.view(torch.uint8)
+        out[base + 16:base + 16 + MATCH_BYTES * n] = matches[f, :MATCH_BYTES * n]
+        out[base + off_idx:base + off_idx + 4 * n] = idx[f, :n].contiguous().view(torch.uint8)
+    return out
+
+
+def unpack_compact(gathered: torch.Tensor, batch: int, cap: int = COMPACT_CAP):
+    """gathered (world, compact_block_bytes) uint8 -> (counter (world,B,3) int32, n (world,B) int32, matches: list[world][B] of (n, 22) uint8,
+    idx: list[world][B] of (n,) int32)."""
+    g = gathered.cpu()
+    w = g.shape[0]
+    slot = compact_slot_bytes(cap)
+    off_idx = (16 + MATCH_BYTES * cap + 3) & ~3
+    slots = g[:, :slot * batch].reshape(w, batch, slot)
+    head = slots[:, :, :16].contiguous().view(torch.int32).view(w, batch, 4)
+    counter, n = head[:, :, :3].contiguous(), head[:, :, 3].contiguous()
+    matches = [[slots[r, f, 16:16 + MATCH_BYTES * int(n[r, f])].reshape(-1, MATCH_BYTES) for f in range(batch)] for r in range(w)]
+    idx = [[slots[r, f, off_idx:off_idx + 4 * int(n[r, f])].contiguous().view(torch.int32) for f in range(batch)] for r in range(w)]
+    return counter, n, matches, idx
+
+
 def gather_records(record: torch.Tensor, gathered: torch.Tensor, dist, async_op: bool = False):
     """All-gather the per-rank record block: one collective per step, equal counts on every rank.
     async_op=True returns the work handle: the collective then runs beside the next step's kernels (RCCL: its own stream);
     the caller waits on the handle before it reuses `record` / reads `gathered`."""
     # flattened views: (world * B, bytes) <- (B, bytes); the gloo backend insists on the concatenated shape, RCCL accepts it too
+    if record.dim() == 1:  # one flat block per rank (compact records)
+        work = dist.all_gather_into_tensor(gathered.view(-1), record, async_op=async_op)
+        return work if async_op else gathered
     work = dist.all_gather_into_tensor(gathered.view(-1, gathered.shape[-1]), record, async_op=async_op)
     return work if async_op else gathered
 
