@@ -484,7 +484,9 @@ def main():
 
     # synthetic feeds: distinct seeds per rank and frame, uploaded once (inputs resident in HBM before the timed region)
     feeds = vp.feeds
-    raws = np.stack([cfg.synth(feeds.feed_seed(rank, i)) for i in range(B)])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(16, host_cores() // max(1, world)))) as pool:  # the renderer is C++ behind ctypes: the GIL is released
+        raws = np.stack(list(pool.map(lambda i: cfg.synth(feeds.feed_seed(rank, i)), range(B))))
     d_raw = torch.from_numpy(raws).cuda()
     # every buffer vp_frame writes comes from the library's allocator, as a deployment's would: allocated once, the table and flat from
     # placement-checked blocks (vp_frame_buffers_create; --plain-alloc: take what hipMalloc gives, the round-2 behaviour)

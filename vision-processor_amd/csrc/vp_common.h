@@ -59,7 +59,7 @@ struct VpFrameGraph {
 	std::vector<uint8_t> key; // stream, batch, parameters, raw pointer, buffers, tuning
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t exec = nullptr;
-	bool failed = false;       // capture was refused once: this tuple stays on the ordinary path
+	int refused = 0;           // captures that did not come about; after three the tuple stays on the ordinary path
 	uint64_t ws_generation = 0, sat_shape = 0;
 	uint32_t sat_tickets = 0;
 	unsigned char map_key[96] = {};

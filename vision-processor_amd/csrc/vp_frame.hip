@@ -77,12 +77,12 @@ static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, con
 		graph_drop(*g); // something the captured launches rely on has moved: ordinary path now, capture again next time
 		return frame_body(ctx, stream, p, raw, batch, b);
 	}
-	if(g->failed || poisoned) return frame_body(ctx, stream, p, raw, batch, b);
+	if(g->refused >= 3 || poisoned) return frame_body(ctx, stream, p, raw, batch, b);
 	// second sighting: capture.  A reset of the SAT state or a growing workspace inside the capture is refused by those functions (ctx->capturing) and lands here as a failure.
 	hipStream_t s = ctx->streams[stream];
 	if(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
 		(void)hipGetLastError();
-		g->failed = true;
+		g->refused = 3; // this stream cannot be captured at all
 		return frame_body(ctx, stream, p, raw, batch, b);
 	}
 	ctx->capturing[stream] = true;
@@ -95,7 +95,7 @@ static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, con
 		(void)hipGetLastError();
 		if(graph) (void)hipGraphDestroy(graph);
 		g->exec = nullptr;
-		g->failed = true;
+		g->refused++; // e.g. another shape ran on the stream in between and the SAT state has to be reset first: the ordinary call below does that, try again next time
 		ctx->sat_epoch[stream] = epoch_before; // nothing was launched
 		return frame_body(ctx, stream, p, raw, batch, b);
 	}
