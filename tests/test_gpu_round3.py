@@ -470,3 +470,42 @@ def test_records_compact_is_what_the_host_loop_reads(env):
         slab.destroy()
     finally:
         ctx.close()
+
+
+def test_a_refused_frame_leaves_the_callers_buffers_untouched(env):
+    """vp_frame checks every argument before it sizes a workspace or enqueues a kernel (the reference's FATAL convention, log.h:21, turned into a
+    status at the C ABI): a refused call must not have overwritten flat, cleared the counters or launched anything."""
+    capi, torch = env
+    cfg = cfgs.T_MID
+    B, mm = 2, cfg.max_matches
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        raws = dev(torch, np.stack([cfg.synth(900 + i) for i in range(B)]))
+        flat = torch.full((B, cfg.fh, cfg.fw, 4), 0xAB, dtype=torch.uint8, device="cuda")
+        sat = torch.full((B, cfg.fh, cfg.fw), 0x11111111, dtype=torch.int32, device="cuda")
+        m = torch.full((B, mm * 22), 0xCD, dtype=torch.uint8, device="cuda")
+        idx = torch.full((B, mm), 7, dtype=torch.int32, device="cuda")
+        cnt = torch.full((B, 3), -77, dtype=torch.int32, device="cuda")
+
+        def bad(**over):
+            p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
+            for k, v in over.items():
+                setattr(p, k, v)
+            return p
+        cases_ = [(bad(order=5), B), (bad(fw=-64), B), (bad(fh=0), B), (bad(max_matches=0), B), (bad(layout=9), B), (bad(sampler_mode=3), B), (bad(sat_variant=7), B),
+                  (bad(grad_offset=-1), B), (bad(qw=0), B), (bad(), 0), (bad(), 70000)]
+        for p, batch in cases_:
+            with pytest.raises(capi.VpError) as e:
+                ctx.frame(p, raws, batch, flat, sat, m, cnt, idx=idx)
+            assert e.value.code == -1
+        with pytest.raises(capi.VpError):  # VP_SAT_LOCAL with a table buffer
+            ctx.frame(capi.frame_params(cfg, sat_variant=capi.SAT_LOCAL), raws, B, flat, sat, m, cnt, idx=idx)
+        with pytest.raises(capi.VpError):  # records at an odd address
+            ctx.frame(bad(), raws, B, flat, sat, m.view(-1)[1:].data_ptr(), cnt, idx=idx)
+        ctx.sync()
+        assert bool((flat == 0xAB).all()) and bool((sat == 0x11111111).all()) and bool((m == 0xCD).all()) and bool((idx == 7).all()) and bool((cnt == -77).all())
+        ctx.frame(bad(), raws, B, flat, sat, m, cnt, idx=idx)  # and the context still works
+        ctx.sync()
+        assert int(cnt[:, 0].min()) > 0 and not bool((flat == 0xAB).all())
+    finally:
+        ctx.close()

@@ -183,6 +183,13 @@ int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out,
 			return VP_ERR_NOMEM;
 		}
 		w.bytes = want;
+		// a workspace on another device would be read over xGMI on every launch, silently: a caller that drives several contexts from one thread
+		// (host/feeds_multi.cpp in round 2) is exactly how that happens, and a one-GPU box cannot show it -- so check where the block landed
+		hipPointerAttribute_t attr;
+		if(hipPointerGetAttributes(&attr, w.ptr) == hipSuccess && attr.device != ctx->device) {
+			vp_set_error("workspace of a context on device %d was allocated on device %d", ctx->device, attr.device);
+			return VP_ERR_HIP;
+		}
 		VP_CHECK_HIP(hipMemsetAsync(w.ptr, 0, want, ctx->streams[stream]));
 	}
 	*out = w.ptr;
