@@ -17,9 +17,11 @@ for kv in a.tune:
     ctx.tune(kv.split("=")[0], int(kv.split("=")[1]))
 raw4 = torch.from_numpy(np.stack([cfg.synth(i) for i in range(4)])).cuda()
 raw = raw4.repeat((B + 3) // 4, *([1] * (raw4.dim() - 1)))[:B].contiguous()
-d = dict(flat=torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"), sat=torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda"),
-         matches=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"), idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"), counter=torch.zeros((B, 3), dtype=torch.int32, device="cuda"))
 p = capi.frame_params(cfg, sat_variant=variant)
+slab = ctx.frame_slab(capi.frame_params(cfg), B)  # the library's allocator: the table and flat from placement-checked blocks when they are large
+_flat, _sat, _m, _idx, _cnt = slab.torch_views()
+d = dict(flat=_flat, sat=_sat, matches=_m, idx=_idx, counter=_cnt)
+print("placement:", slab.placement["sat"], flush=True)
 ctx.frame(p, raw, B, **d); ctx.sync()
 d_map = torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda")
 ctx.resample_map(cfg.model(), cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, d_map)
