@@ -363,3 +363,54 @@ def test_blob_centres_hit_the_rendered_discs(port):
     assert st["residual_rms_px"] < 0.35 and st["residual_max_px"] < 1.0, st
     for kind in ("centre", "side", "ball"):
         assert st[kind]["max_mm"] < 1.5 * cfg.field_scale, (kind, st[kind])
+
+
+def test_batch_step_from_compact_slots_equals_the_batch_step_from_full_arrays(port):
+    """vph_detect_batch_slots (compact record slots in, packet slots out: what vp_feeds reads back and gathers) produces, feed by feed and step by
+    step, the very packets vph_detect_batch produces from the fixed-capacity arrays; a slot too small for its frame is refused, not truncated."""
+    import oracle as HO
+    import torch
+    feeds_mod = cases.vp.feeds
+    cfg = cases.cfgs.T_MID
+    model = HO.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    n, mm, cap, pslot = 3, 400, 96, 2048
+    counters = np.zeros((n, 3), np.int32)
+    matches = np.zeros((n, 22 * mm), np.uint8)
+    idx = np.zeros((n, mm), np.int32)
+    for i in range(n):
+        m, ix, c = port.frame(cfg.synth(120 + i), cfg.layout, cfg.qw, cfg.qh, model, 180.0, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh, cfg.grad_offset,
+                              cfg.circle_radius, cfg.list_radius, 15.0, 0.0, mm)
+        counters[i] = c
+        matches[i, :22 * len(m)] = np.frombuffer(m.tobytes(), np.uint8)
+        idx[i, :len(ix)] = ix.view(np.int32)
+    assert 0 < int(counters[:, 0].max()) <= cap
+
+    def detectors():
+        out = []
+        for i in range(n):
+            dc = H.config_defaults()
+            dc.cam_id = 7 + i
+            d = H.Detector(dc)
+            d.set_geometry_direct(H.nadir_calib(cfg.model()), (cfg.qw, cfg.qh), cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh)
+            out.append(d)
+        return out
+    da, db = detectors(), detectors()
+    block = feeds_mod.pack_compact_host(torch.from_numpy(counters), torch.from_numpy(matches), torch.from_numpy(idx), cap).numpy()
+    slot = feeds_mod.compact_slot_bytes(cap)
+    for step in range(1, 4):  # colour model and tracker carried along in both sets of detectors
+        t = step / 70.0
+        pk = np.zeros((n, pslot - 4), np.uint8)
+        ln = np.zeros(n, np.int32)
+        H.detect_batch(da, matches, counters, mm, step, t, t, t + 0.002, 2, pk, ln)
+        pb = np.zeros(n * pslot, np.uint8)
+        assert H.detect_batch_slots(db, block, slot, mm, step, t, t, t + 0.002, 3, pb, pslot) == 0
+        for i in range(n):
+            length = int(pb[i * pslot:i * pslot + 4].view(np.int32)[0])
+            assert length == int(ln[i]) > 0 and pb[i * pslot + 4:i * pslot + 4 + length].tobytes() == pk[i, :length].tobytes(), (step, i)
+    # a slot that holds fewer records than the host loop would read (main.cpp:301) is an error, nothing runs
+    small = feeds_mod.pack_compact_host(torch.from_numpy(counters), torch.from_numpy(matches), torch.from_numpy(idx), 8).numpy()
+    assert H.detect_batch_slots(db, small, feeds_mod.compact_slot_bytes(8), mm, 9, 0.1, 0.1, 0.1, 1, np.zeros(n * pslot, np.uint8), pslot) != 0
+    # a packet slot too small for the packet: length = -needed, payload untouched
+    tiny = np.full(n * 64, 0xEE, np.uint8)
+    assert H.detect_batch_slots(db, block, slot, mm, 10, 0.2, 0.2, 0.2, 1, tiny, 64) == 0
+    assert all(int(tiny[i * 64:i * 64 + 4].view(np.int32)[0]) < -60 and int(tiny[i * 64 + 4]) == 0xEE for i in range(n))

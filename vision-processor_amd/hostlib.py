@@ -340,3 +340,15 @@ def detect_batch(detectors, cl_matches: np.ndarray, counters: np.ndarray, max_ma
                                  int(packets.shape[1]), lengths.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError(f"vph_detect_batch failed: {rc}")
+
+
+def detect_batch_slots(detectors, slots: np.ndarray, slot_bytes: int, max_matches: int, frame_id: int, start_time: float, img_timestamp: float, t_sent: float,
+                       threads: int, packet_block: np.ndarray, packet_slot_bytes: int):
+    """vph_detect_batch_slots: the same step with the transport forms on both sides -- compact record slots in (vp_records_compact), packet slots
+    [int32 length | bytes] out.  Returns the library's status (0 = ok; negative when a record slot was too small for its frame)."""
+    n = len(detectors)
+    assert slots.dtype == np.uint8 and slots.flags.c_contiguous and slots.size >= n * slot_bytes
+    assert packet_block.dtype == np.uint8 and packet_block.flags.c_contiguous and packet_block.size >= n * packet_slot_bytes
+    hs = (C.c_void_p * n)(*[d.h for d in detectors])
+    return int(_vph().vph_detect_batch_slots(hs, n, slots.ctypes.data_as(C.c_void_p), C.c_size_t(slot_bytes), int(max_matches), C.c_uint32(frame_id), C.c_double(start_time),
+                                             C.c_double(img_timestamp), C.c_double(t_sent), int(threads), packet_block.ctypes.data_as(C.c_void_p), int(packet_slot_bytes)))
