@@ -10,9 +10,10 @@ cfg = vp.configs.ALL[os.environ.get("VP_CFG", "cfg2_2048x1536_rggb")]
 B = int(sys.argv[1]); mm = cfg.max_matches
 raw4 = torch.from_numpy(np.stack([cfg.synth(i) for i in range(4)])).cuda()
 raw = raw4.repeat((B + 3) // 4, 1, 1)[:B].contiguous()
-flat = torch.empty((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda"); sat = torch.empty((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
-m = torch.zeros((B, 22 * mm), dtype=torch.uint8, device="cuda"); idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda"); c = torch.zeros((B, 3), dtype=torch.int32, device="cuda")
 p = capi.frame_params(cfg)
+_ctx0 = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+slab = _ctx0.frame_slab(p, B)  # the library's allocator (placement-checked blocks for large launch groups)
+flat, sat, m, idx, c = slab.torch_views()
 for setting in sys.argv[2:] or ["default"]:
     ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
     if setting != "default":
