@@ -97,10 +97,15 @@ const char* vp_device_name(VpContext* ctx);
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
  *   write the dense halo strips the tiled SAT pass reads), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
- *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 (default 0: vp_frame captures the launches of a repeated (stream, parameters, batch,
- *   buffers) call into a hipGraph the second time it sees it and replays the graph from then on; calls with stage events enabled or debug views take the
- *   ordinary path).  Applies to calls issued after it. */
+ *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 / 2 (default 0; 1: vp_frame captures the launches of a (stream, parameters, batch,
+ *   buffers) call into a hipGraph when the call follows itself on the stream and replays the graph from then on; a stream whose state belongs to another
+ *   tuple -- another launch shape, another geometry -- takes the ordinary path, which repairs it; calls with stage events enabled or debug views always
+ *   do.  2 = the same without the pre-flight check: every repeated tuple attempts a capture, and a capture that meets a repair is refused and undone --
+ *   slower, for tests of that path).  Applies to calls issued after it. */
 int vp_ctx_tune(VpContext* ctx, const char* key, int value);
+/* "frame_graph" bookkeeping since the context was created: out = {captures made, replays launched, captures refused and undone, graphs dropped because the
+ * stream's state had moved}. */
+int vp_frame_graph_stats(VpContext* ctx, int64_t out[4]);
 
 /* per-launch timing, the analogue of the stored cl::Event list (opencl.h:84, opencl.cpp:94-105).  When enabled every
  * stage launch is bracketed by hipEvents; vp_event_times syncs the stream and returns up to `cap` {tag, ms} pairs. */

@@ -264,31 +264,13 @@ def test_frame_buffers_allocator(env, port):
         ctx.close()
 
 
-def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
-    """BASELINE configs[3] as written, in C++ on the C ABIs alone: `vp_feeds --gpus N --detect` (N = every visible device) -- one driver thread per
-    device, vp_frame -> compact record slots -> CPU hypothesis stage -> SSL_WrapperPacket slots -> ONE grouped ncclAllGather per step through real
-    RCCL.  The program checks that every device received every owner's block byte for byte (--verify); here the packets the LAST device received
-    in the last step are parsed with google.protobuf and held to the CPU checkers for the same feed seeds: the hot-path oracle's blob list pushed
-    through oracle/detect_oracle.py for the same number of steps (colour model and tracker carried along), binary32 fields bit for bit.  Replaces
-    main.cpp:319-370 + udpsocket.cpp:94-100; the gather block is 13 x smaller than the raw record arrays."""
-    import json
-    import torch
+def check_gathered_packets(blob, n, feeds, slot, total, oracle_ranks=2):
+    """What one device received in the last step of `vp_feeds --gpus n --detect` (n rank blocks of `feeds` packet slots): every slot parses with
+    google.protobuf, and for every feed of the first `oracle_ranks` ranks (one feed of the others) the detection equals, binary32 field by field, the
+    hot-path oracle's blob list of that feed's seed pushed through oracle/detect_oracle.py for `total` steps (colour model and tracker carried along)."""
     import detect_oracle as D
     import test_detection_stage as S
     import test_wire_format as W
-    n = torch.cuda.device_count()
-    exe = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_feeds")
-    envv = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    feeds, steps, warmup = 3, 3, 1
-    dump = str(tmp_path / "gathered.bin")
-    out = subprocess.run([exe, "--gpus", str(n), str(feeds), str(steps), str(warmup), "--detect", "--threads", "8", "--verify", "--dump", dump], capture_output=True, text=True, timeout=900, env=envv)
-    assert out.returncode == 0, out.stdout + out.stderr
-    r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["gpus"] == n and r["gather_verified"] is True and r["block"] == "SSL_WrapperPacket slots" and "ncclAllGather" in r["gather"]
-    assert r["record_bytes_per_gpu"] * 10 <= r["full_record_bytes_per_gpu"]
-    assert r["detect"]["robots_per_frame"] == 16.0 and 8.0 <= r["detect"]["balls_per_frame"] <= 9.0 and 500 < r["detect"]["packet_bytes_per_frame"] < 1500
-    slot = r["detect"]["packet_slot_bytes"]
-    blob = open(dump, "rb").read()
     block = len(blob) // n
     assert len(blob) == n * block and block >= feeds * slot
     cfg, mm = CFG, CFG.max_matches
@@ -298,7 +280,6 @@ def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
     calib = (mdl.f, mdl.p[0], mdl.p[1], mdl.d, -1.0, 0.0, 0.0, 0.0, -mdl.c[0], mdl.c[1], mdl.c[2])
     F = np.float32
     fs, ox, oy = F(cfg.field_scale), F(cfg.off_x), F(cfg.off_y)
-    total = warmup + steps
     for g in range(n):
         for i in range(feeds):
             off = g * block + i * slot
@@ -309,7 +290,7 @@ def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
             assert pkt.IsInitialized() and pkt.source == 3
             d = pkt.detection
             assert d.camera_id == g * feeds + i and d.frame_number == total
-            if g >= 2 and i > 0:
+            if g >= oracle_ranks and i > 0:
                 continue  # the oracle comparison covers every feed of two devices and one feed of the others
             m, _, cnt = big.frame(cfg.synth(cases.vp.feeds.feed_seed(g, i)), cfg.layout, cfg.qw, cfg.qh, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y,
                                   cfg.sampler_mode, cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
@@ -333,12 +314,36 @@ def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
             assert len(d.robots_yellow) + len(d.robots_blue) == 16
 
 
+def test_config3_native_feeds_gather_the_oracles_detection_packets(tmp_path):
+    """BASELINE configs[3] as written, in C++ on the C ABIs alone: `vp_feeds --gpus N --detect` (N = every visible device) -- one driver thread per
+    device, vp_frame -> compact record slots -> CPU hypothesis stage -> SSL_WrapperPacket slots -> ONE grouped ncclAllGather per step through real
+    RCCL.  The program checks that every device received every owner's block byte for byte (--verify); here the packets the LAST device received
+    in the last step are parsed with google.protobuf and held to the CPU checkers for the same feed seeds: the hot-path oracle's blob list pushed
+    through oracle/detect_oracle.py for the same number of steps (colour model and tracker carried along), binary32 fields bit for bit.  Replaces
+    main.cpp:319-370 + udpsocket.cpp:94-100; the gather block is 13 x smaller than the raw record arrays."""
+    import json
+    import torch
+    n = torch.cuda.device_count()
+    exe = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_feeds")
+    envv = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    feeds, steps, warmup = 3, 3, 1
+    dump = str(tmp_path / "gathered.bin")
+    out = subprocess.run([exe, "--gpus", str(n), str(feeds), str(steps), str(warmup), "--detect", "--threads", "8", "--verify", "--dump", dump], capture_output=True, text=True, timeout=900, env=envv)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["gpus"] == n and r["gather_verified"] is True and r["block"] == "SSL_WrapperPacket slots" and "ncclAllGather" in r["gather"]
+    assert r["record_bytes_per_gpu"] * 10 <= r["full_record_bytes_per_gpu"]
+    assert r["detect"]["robots_per_frame"] == 16.0 and 8.0 <= r["detect"]["balls_per_frame"] <= 9.0 and 500 < r["detect"]["packet_bytes_per_frame"] < 1500
+    check_gathered_packets(open(dump, "rb").read(), n, feeds, r["detect"]["packet_slot_bytes"], warmup + steps)
+
+
 @pytest.mark.parametrize("variant", ["tiled", "local"])
 def test_frame_graph_replay_is_result_neutral(env, port, variant):
     """vp_ctx_tune "frame_graph": vp_frame captures the launches of a repeated (stream, parameters, batch, buffers) call into a hipGraph the second
     time it sees it and replays it afterwards (nothing that changes between calls is a kernel argument: the single-pass SAT derives its epoch and
-    ticket base from the tickets it draws).  Four library-owned streams, two geometries taking turns on every stream (a replay must notice that the
-    stream's coordinate map was rebuilt for the other geometry and that the SAT shape changed), eight rounds, new sensor frames written into the same
+    ticket base from the tickets it draws).  Four library-owned streams, two geometries OF THE SAME SIZE taking turns on every stream (a replay must
+    notice that the stream's coordinate map was rebuilt for the other geometry; launch shapes that differ in size or batch:
+    test_gpu_round4.py::test_frame_graph_alternating_launch_shapes_on_one_stream), eight rounds, new sensor frames written into the same
     device buffers between rounds: every result equals the CPU oracle's -- flat, SAT, counters, sorted records.  One loop per camera: main.cpp:262-317."""
     capi, torch = env
     cfg_a, cfg_b = cfgs.T_MID, cfgs.T_MID.with_(name="t_mid_shifted", off_x=-1400.0, off_y=-850.0)

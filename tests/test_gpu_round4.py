@@ -1,0 +1,163 @@
+"""GPU tests added in round 4, all through the C ABI or the C++ programs built on it.
+
+  * THE N > 1 HOST PIPELINE EXECUTES: `vp_feeds --gpus 2 --same-device` -- two driver threads, two contexts, two detector sets, the step rendezvous, the
+    gather issued by whichever thread arrives last, slot reuse two steps later and the end-of-run drain (host/feeds_multi.cpp), with the all-gather done
+    by the TEST-ONLY loop-back constructor of include/vp_multi.h (both ranks on device 0, device-to-device copies; real RCCL needs two devices).  Both
+    ranks' packets / records are held to the CPU oracle for feed_seed(0, .) and feed_seed(1, .).  Replaces one process per camera, main.cpp:262-370 +
+    udpsocket.cpp:94-100, 147-163.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+from test_gpu_round3 import check_gathered_packets
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+CFG = cfgs.CFG2
+EXE = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_feeds")
+
+
+def run_feeds(*args, timeout=900):
+    envv = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([EXE, *[str(a) for a in args]], capture_output=True, text=True, timeout=timeout, env=envv)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+
+@pytest.mark.parametrize("local", [False, True])
+def test_two_ranks_on_one_device_gather_the_oracles_detection_packets(tmp_path, local):
+    """`vp_feeds --gpus 2 --same-device --detect --verify --dump`: 1 warm-up + 4 timed steps, so every slot of the double-buffered gather is reused
+    twice and the last step's CPU stage runs with no GPU step behind it.  --verify: both ranks received both blocks byte for byte; the dump of rank 1's
+    receive area parses (google.protobuf) to the oracle's detections for BOTH ranks' feeds."""
+    feeds, steps, warmup = 3, 4, 1
+    dump = str(tmp_path / "gathered.bin")
+    r, _ = run_feeds("--gpus", 2, "--same-device", feeds, steps, warmup, "--detect", "--threads", 8, "--verify", "--dump", dump, *(["--local"] if local else []))
+    assert r["gpus"] == 2 and r["same_device"] is True and "loop-back" in r["gather"] and "RCCL" not in r["gather"].replace("no RCCL", "")
+    assert r["gather_verified"] is True and r["block"] == "SSL_WrapperPacket slots" and r["sat_variant"] == ("local" if local else "tiled")
+    assert r["detect"]["robots_per_frame"] == 16.0 and r["detect"]["steps_reread_at_full_capacity"] == 0
+    check_gathered_packets(open(dump, "rb").read(), 2, feeds, r["detect"]["packet_slot_bytes"], warmup + steps)
+
+
+def test_two_ranks_on_one_device_gather_the_oracles_records(tmp_path):
+    """The same pipeline without the CPU stage: every rank's compact record block (vp_records_compact straight into the gather block) arrives at both
+    ranks; rank 1's receive area holds, for every feed of both ranks, the oracle's counters and raster-sorted records + pixel indices."""
+    f = cases.vp.feeds
+    feeds, steps, warmup, cap = 3, 5, 2, 192
+    dump = str(tmp_path / "records.bin")
+    r, _ = run_feeds("--gpus", 2, "--same-device", feeds, steps, warmup, "--verify", "--dump", dump, "--cap", cap)
+    assert r["gather_verified"] is True and r["block"] == "compact records" and r["truncated_slots_last_step"] == 0 and r["same_device"] is True
+    blob = np.frombuffer(open(dump, "rb").read(), np.uint8)
+    block = r["record_bytes_per_gpu"]
+    assert blob.size == 2 * block
+    slot = f.compact_slot_bytes(cap)
+    off_i = (16 + 22 * cap + 3) & ~3
+    cfg, mm = CFG, CFG.max_matches
+    big = O.Port(threads=min(16, os.cpu_count() or 1))
+    model_o = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    for g in range(2):
+        for i in range(feeds):
+            m, idx, cnt = big.frame(cfg.synth(f.feed_seed(g, i)), cfg.layout, cfg.qw, cfg.qh, model_o, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y,
+                                    cfg.sampler_mode, cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+            s = blob[g * block + i * slot:g * block + (i + 1) * slot]
+            head = s[:16].view(np.int32)
+            n = int(cnt[0])
+            assert head[:3].tolist() == [int(v) for v in cnt] and head[3] == n and r["counters"][g][i] == head[:3].tolist(), (g, i)
+            assert s[16:16 + 22 * n].tobytes() == m.tobytes() and np.array_equal(s[off_i:off_i + 4 * n].view(np.uint32), idx), (g, i)
+
+
+def test_a_frame_with_more_blobs_than_the_slot_is_reread_not_dropped(tmp_path):
+    """--cap 8 (every cfg2 frame has ~130 blobs): the compact slots cannot hold what the host loop reads (main.cpp:301: min(counter[0], maxBlobs)
+    records).  With --detect every step is read once more at full capacity and the packets are still the oracle's; without --detect the truncated
+    slots are counted in the report."""
+    feeds, steps, warmup = 2, 2, 1
+    dump = str(tmp_path / "gathered.bin")
+    r, _ = run_feeds("--gpus", 2, "--same-device", feeds, steps, warmup, "--detect", "--threads", 4, "--verify", "--dump", dump, "--cap", 8)
+    assert r["gather_verified"] is True and r["detect"]["steps_reread_at_full_capacity"] == 2 * (steps + warmup) and r["detect"]["robots_per_frame"] == 16.0
+    check_gathered_packets(open(dump, "rb").read(), 2, feeds, r["detect"]["packet_slot_bytes"], warmup + steps, oracle_ranks=1)
+    r2, err = run_feeds("--gpus", 2, "--same-device", feeds, steps, warmup, "--verify", "--cap", 8)
+    assert r2["truncated_slots_last_step"] == 2 * feeds and "raise --cap" in err
+
+
+# ---- vp_ctx_tune "frame_graph": a refused capture must leave no host state behind ---------------------------------------------------------------
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return cases.vp.load_capi(), torch
+
+
+def _no_walker(cfg, fs=1.5):
+    """a geometry whose (circle radius, gradient offset) pair has no k_flat_walk instance (r = 14, o = 5): VP_SAT_LOCAL goes through the private table"""
+    return cfg.with_(name=cfg.name + f"_fs{fs}", field_scale=fs, off_x=-cfg.fw / 2 * fs, off_y=-cfg.fh / 2 * fs, visible_len=cfg.fw * fs * 1.05)
+
+
+GRAPH_SEQ = "ABABACAAABBBCCABCA"  # second sightings right after another shape (A B A), after another geometry (A C A), runs of replays, and mixes
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("variant", ["tiled", "local", "local_private_table", "twopass"])
+def test_frame_graph_alternating_launch_shapes_on_one_stream(env, port, variant, mode):
+    """frame_graph = 1 on ONE stream, three (parameters, batch) tuples taking turns: A = 640x384 x 2 frames, B = 704x448 x 3 frames (another tile grid AND
+    batch: the single-pass SAT's ticket counters, tile order and carry granules must be reset whenever the shape changes), C = A's shape with a shifted
+    geometry (the stream's coordinate map must be rebuilt).  mode 1: a tuple is captured only when it follows itself (pre-flight: the stream's state is
+    the tuple's own); mode 2: every repeated tuple attempts a capture, a capture that meets either need is refused, and the refusal must leave no trace --
+    the call that follows it on the ordinary path has to see the stream as it was (round 3 left sat_shape / sat_tickets / map_key behind: the retry then
+    skipped the reset and the map).  Every call's flat, table, counters and sorted records equal the CPU oracle's; vp_sync never reports a look-back timeout.
+    "local_private_table": VP_SAT_LOCAL for an (r, o) pair without a walker uses the same single-pass state through a private table.  main.cpp:262-289."""
+    capi, torch = env
+    base = cfgs.T_MID
+    if variant == "local_private_table":
+        base = _no_walker(base)
+        assert (base.circle_radius, base.grad_offset) == (14, 5)
+    big = base.with_(name=base.name + "_704x448", fw=704, fh=448)
+    shifted = base.with_(name=base.name + "_shifted", off_x=base.off_x + 100.0, off_y=base.off_y + 50.0)
+    tuples = {"A": (base, 2), "B": (big, 3), "C": (shifted, 2)}
+    sv = {"tiled": capi.SAT_TILED, "twopass": capi.SAT_TWOPASS}.get(variant, capi.SAT_LOCAL)
+    with_sat = sv != capi.SAT_LOCAL
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        ctx.tune("frame_graph", mode)
+        bufs, params, models = {}, {}, {}
+        for k, (c, B) in tuples.items():
+            mm = c.max_matches
+            bufs[k] = dict(raw=torch.zeros((B,) + c.sensor_shape, dtype=torch.uint8, device="cuda"), flat=torch.zeros((B, c.fh, c.fw, 4), dtype=torch.uint8, device="cuda"),
+                           sat=torch.zeros((B, c.fh, c.fw), dtype=torch.int32, device="cuda") if with_sat else None, m=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"),
+                           idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"), cnt=torch.full((B, 3), -5, dtype=torch.int32, device="cuda"))
+            params[k] = capi.frame_params(c, sat_variant=sv, order=capi.ORDER_RASTER)
+            models[k] = O.CameraModel.from_array(np.frombuffer(bytes(c.model()), np.uint8))
+        for rnd, k in enumerate(GRAPH_SEQ):
+            cfg, B = tuples[k]
+            mm = cfg.max_matches
+            raws = [cfg.synth(9000 + 10 * rnd + j) for j in range(B)]
+            b = bufs[k]
+            b["raw"].copy_(torch.from_numpy(np.stack(raws)))
+            torch.cuda.synchronize()
+            ctx.frame(params[k], b["raw"], B, b["flat"], b["sat"], b["m"], b["cnt"], idx=b["idx"])
+            ctx.sync()  # raises on VP_ERR_TIMEOUT
+            for j in range(B):
+                s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+                wm, widx, wcnt = port.frame(raws[j], cfg.layout, cfg.qw, cfg.qh, models[k], cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                            cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+                assert np.array_equal(b["flat"][j].cpu().numpy(), s["flat"]), (rnd, k, j, "flat")
+                if with_sat:
+                    assert np.array_equal(b["sat"][j].cpu().numpy(), port.sat_i32(s["graddot"])[0]), (rnd, k, j, "sat")
+                cnt = b["cnt"][j].cpu().numpy()
+                assert np.array_equal(cnt, wcnt), (rnd, k, j, cnt, wcnt)
+                n = min(int(cnt[0]), mm)
+                assert np.array_equal(b["idx"][j].cpu().numpy().view(np.uint32)[:n], widx) and b["m"][j].cpu().numpy()[:22 * n].tobytes() == wm.tobytes(), (rnd, k, j)
+        stats = ctx.graph_stats()
+        # the sequence really exercised the outcomes: captures, replays, graphs dropped because another tuple had used the stream -- and, without the
+        # pre-flight, captures refused and undone
+        assert stats["captures"] >= 2 and stats["replays"] >= 2 and stats["dropped"] >= 2 and (stats["refused"] >= 3 if mode == 2 else stats["refused"] == 0), stats
+    finally:
+        ctx.close()

@@ -145,6 +145,11 @@ class Context:
         """vp_ctx_tune: result-neutral knobs (tile mappings, resident workgroups, list capacity); the library reads no environment variable."""
         self._ck(self.l.vp_ctx_tune(self.h, key.encode(), int(value)))
 
+    def graph_stats(self):
+        out = (C.c_int64 * 4)()
+        self._ck(self.l.vp_frame_graph_stats(self.h, out))
+        return dict(captures=out[0], replays=out[1], refused=out[2], dropped=out[3])
+
     # ---- memory -----------------------------------------------------------------------------------------------------
     def malloc(self, nbytes) -> int:
         p = C.c_void_p()

@@ -50,7 +50,7 @@ struct VpTuning {
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
-	int frame_graph = 0;           // vp_frame replays a captured hipGraph of its launches for a repeated (stream, parameters, batch, buffers) tuple
+	int frame_graph = 0;           // vp_frame replays a captured hipGraph of its launches for a repeated (stream, parameters, batch, buffers) tuple (2: no pre-flight, see vp_frame.hip)
 	int placement_candidates = 48; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives)
 };
 
@@ -59,7 +59,8 @@ struct VpFrameGraph {
 	std::vector<uint8_t> key; // stream, batch, parameters, raw pointer, buffers, tuning
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t exec = nullptr;
-	int refused = 0;           // captures that did not come about; after three the tuple stays on the ordinary path
+	int refused = 0;           // captures the runtime could not make; after three the tuple stays on the ordinary path
+	bool noted = false;        // the fields below hold the stream state the tuple's launches need (recorded after each ordinary call / capture)
 	uint64_t ws_generation = 0, sat_shape = 0;
 	uint32_t sat_tickets = 0;
 	unsigned char map_key[96] = {};
@@ -79,6 +80,7 @@ struct VpContext {
 	uint64_t ws_generation[VP_MAX_STREAMS] = {};   // bumped whenever a workspace of the stream is (re)allocated: captured graphs hold the old pointers
 	bool capturing[VP_MAX_STREAMS] = {};           // a vp_frame launch sequence is being captured on the stream: nothing may synchronise, allocate or reset
 	std::vector<VpFrameGraph> graphs;
+	int64_t graph_stats[4] = {};                   // captures, replays, refused captures, dropped graphs (vp_frame_graph_stats)
 	int* host_flag[VP_MAX_STREAMS] = {};           // pinned, device-mapped word the SAT kernel raises on a look-back timeout
 	std::string device_name;
 	int cu_count = 0;

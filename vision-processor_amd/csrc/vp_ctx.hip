@@ -122,7 +122,7 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 		VP_REQUIRE(value == 0 || value == 1, "vp_ctx_tune: sat_halo_strips is 0 or 1");
 		ctx->tune.sat_halo_strips = value;
 	} else if(k == "frame_graph") {
-		VP_REQUIRE(value == 0 || value == 1, "vp_ctx_tune: frame_graph is 0 or 1");
+		VP_REQUIRE(value >= 0 && value <= 2, "vp_ctx_tune: frame_graph is 0, 1 or 2");
 		ctx->tune.frame_graph = value;
 		if(!value) vp_frame_graphs_clear(ctx);
 	} else if(k == "placement_candidates") {
@@ -188,6 +188,9 @@ int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out,
 		hipPointerAttribute_t attr;
 		if(hipPointerGetAttributes(&attr, w.ptr) == hipSuccess && attr.device != ctx->device) {
 			vp_set_error("workspace of a context on device %d was allocated on device %d", ctx->device, attr.device);
+			(void)hipFree(w.ptr); // do not keep (and later hand out) the misplaced, uninitialised block
+			w.ptr = nullptr;
+			w.bytes = 0;
 			return VP_ERR_HIP;
 		}
 		VP_CHECK_HIP(hipMemsetAsync(w.ptr, 0, want, ctx->streams[stream]));

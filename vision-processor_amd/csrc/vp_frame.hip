@@ -51,7 +51,45 @@ void vp_frame_graphs_clear(VpContext* ctx) {
 	ctx->graphs.clear();
 }
 
+// host-side state of a stream that a vp_frame call advances while it enqueues: a capture that is thrown away must put all of it back, because
+// none of the launches it recorded will ever run
+struct StreamState {
+	unsigned char map_key[96];
+	uint32_t sat_epoch, sat_tickets;
+	uint64_t sat_shape;
+};
+static StreamState stream_state_save(const VpContext* ctx, int stream) {
+	StreamState st;
+	memcpy(st.map_key, ctx->map_key[stream], sizeof(st.map_key));
+	st.sat_epoch = ctx->sat_epoch[stream];
+	st.sat_tickets = ctx->sat_tickets[stream];
+	st.sat_shape = ctx->sat_shape[stream];
+	return st;
+}
+static void stream_state_restore(VpContext* ctx, int stream, const StreamState& st) {
+	memcpy(ctx->map_key[stream], st.map_key, sizeof(st.map_key));
+	ctx->sat_epoch[stream] = st.sat_epoch;
+	ctx->sat_tickets[stream] = st.sat_tickets;
+	ctx->sat_shape[stream] = st.sat_shape;
+}
+
+// what the stream's host-side state must look like for the launches of this tuple to run without a repair (recorded after every ordinary call of the tuple)
+static void graph_note_needs(VpContext* ctx, int stream, VpFrameGraph* g) {
+	g->ws_generation = ctx->ws_generation[stream];
+	memcpy(g->map_key, ctx->map_key[stream], sizeof(g->map_key));
+	g->sat_shape = ctx->sat_shape[stream];
+	g->sat_tickets = ctx->sat_tickets[stream];
+	g->noted = true;
+}
+
+static int frame_ordinary(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b, VpFrameGraph* g) {
+	const int rc = frame_body(ctx, stream, p, raw, batch, b);
+	if(rc == VP_OK) graph_note_needs(ctx, stream, g);
+	return rc;
+}
+
 static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, const uint8_t* raw, int batch, const VpFrameBuffers* b) {
+	VP_CHECK_HIP(hipSetDevice(ctx->device)); // capture and replay act on this context's stream, whatever device the calling thread used last
 	std::vector<uint8_t> key;
 	graph_key(stream, p, raw, batch, b, ctx->tune, key);
 	VpFrameGraph* g = nullptr;
@@ -60,33 +98,44 @@ static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, con
 	if(!g) { // first sighting: the ordinary path (sizes the workspaces, builds the coordinate map, resets the SAT state if the shape is new)
 		if(ctx->graphs.size() >= 64) vp_frame_graphs_clear(ctx);
 		ctx->graphs.emplace_back();
-		ctx->graphs.back().key = key;
-		return frame_body(ctx, stream, p, raw, batch, b);
+		g = &ctx->graphs.back();
+		g->key = key;
+		return frame_ordinary(ctx, stream, p, raw, batch, b, g);
 	}
-	const bool tiled = p->sat_variant == VP_SAT_TILED;
+	// the single-pass SAT state (ticket counters, tile order, carry granules, launch count) is used by VP_SAT_TILED and by VP_SAT_LOCAL calls whose
+	// (radius, offset) pair has no walker: those build a private table with the same kernel (vp_tail.hip, workspace slot 5)
+	const bool tiled = p->sat_variant == VP_SAT_TILED || (p->sat_variant == VP_SAT_LOCAL && !vp_flat_walk_supported(p->circle_radius, p->grad_offset));
 	int* flag = ctx->host_flag[stream];
 	const bool poisoned = flag && *reinterpret_cast<volatile int*>(flag) != 0;
+	// does the stream still look the way this tuple left it?  (another shape resets the SAT state, another geometry rebuilds the map, a grown workspace moves)
+	const bool state_ok = g->noted && g->ws_generation == ctx->ws_generation[stream] && memcmp(g->map_key, ctx->map_key[stream], sizeof(g->map_key)) == 0 &&
+			(!tiled || (g->sat_shape == ctx->sat_shape[stream] && g->sat_tickets == ctx->sat_tickets[stream]));
 	if(g->exec) {
-		const bool near_wrap = tiled && ((uint64_t)ctx->sat_epoch[stream] + 4) * g->sat_tickets >= (uint64_t(1) << 32);
-		if(g->ws_generation == ctx->ws_generation[stream] && memcmp(g->map_key, ctx->map_key[stream], sizeof(g->map_key)) == 0 && (!tiled || (g->sat_shape == ctx->sat_shape[stream] && g->sat_tickets == ctx->sat_tickets[stream])) &&
-				!poisoned && !near_wrap && ctx->sat_epoch[stream] < (1u << 30) - 4) {
+		const bool near_wrap = tiled && (((uint64_t)ctx->sat_epoch[stream] + 4) * g->sat_tickets >= (uint64_t(1) << 32) || ctx->sat_epoch[stream] >= (1u << 30) - 4);
+		if(state_ok && !poisoned && !near_wrap) {
 			if(tiled) ++ctx->sat_epoch[stream]; // the replayed SAT launch draws its tickets like any other
 			VP_CHECK_HIP(hipGraphLaunch(g->exec, ctx->streams[stream]));
+			ctx->graph_stats[1]++;
 			return VP_OK;
 		}
-		graph_drop(*g); // something the captured launches rely on has moved: ordinary path now, capture again next time
-		return frame_body(ctx, stream, p, raw, batch, b);
+		graph_drop(*g); // something the captured launches rely on has moved: ordinary path now (it repairs), capture again next time
+		ctx->graph_stats[3]++;
+		return frame_ordinary(ctx, stream, p, raw, batch, b, g);
 	}
-	if(g->refused >= 3 || poisoned) return frame_body(ctx, stream, p, raw, batch, b);
-	// second sighting: capture.  A reset of the SAT state or a growing workspace inside the capture is refused by those functions (ctx->capturing) and lands here as a failure.
+	// Pre-flight (frame_graph = 1): a stream whose state belongs to another tuple needs a repair that cannot be captured -- take the ordinary path and
+	// capture the next time the tuple follows itself.  frame_graph = 2 skips the pre-flight: every repeated tuple attempts a capture, which exercises the
+	// refusal path below (tests).
+	if(g->refused >= 3 || poisoned || (ctx->tune.frame_graph == 1 && !state_ok)) return frame_ordinary(ctx, stream, p, raw, batch, b, g);
 	hipStream_t s = ctx->streams[stream];
 	if(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
 		(void)hipGetLastError();
 		g->refused = 3; // this stream cannot be captured at all
-		return frame_body(ctx, stream, p, raw, batch, b);
+		return frame_ordinary(ctx, stream, p, raw, batch, b, g);
 	}
+	// A reset of the SAT state, a rebuild of the coordinate map or a growing workspace inside the capture is refused by those functions
+	// (ctx->capturing) BEFORE they change anything; what frame_body advanced up to that point is put back here, because none of the recorded launches will run.
 	ctx->capturing[stream] = true;
-	const uint32_t epoch_before = ctx->sat_epoch[stream];
+	const StreamState before = stream_state_save(ctx, stream);
 	const int rc = frame_body(ctx, stream, p, raw, batch, b);
 	ctx->capturing[stream] = false;
 	hipGraph_t graph = nullptr;
@@ -95,16 +144,22 @@ static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, con
 		(void)hipGetLastError();
 		if(graph) (void)hipGraphDestroy(graph);
 		g->exec = nullptr;
-		g->refused++; // e.g. another shape ran on the stream in between and the SAT state has to be reset first: the ordinary call below does that, try again next time
-		ctx->sat_epoch[stream] = epoch_before; // nothing was launched
-		return frame_body(ctx, stream, p, raw, batch, b);
+		if(rc == VP_OK) g->refused++; // the runtime could not capture / instantiate: a property of the tuple; a refused repair (rc != VP_OK) is not
+		ctx->graph_stats[2]++;
+		stream_state_restore(ctx, stream, before);
+		return frame_ordinary(ctx, stream, p, raw, batch, b, g); // sees the stream as it was and repairs it
 	}
 	g->graph = graph;
-	g->ws_generation = ctx->ws_generation[stream];
-	memcpy(g->map_key, ctx->map_key[stream], sizeof(g->map_key));
-	g->sat_shape = ctx->sat_shape[stream];
-	g->sat_tickets = ctx->sat_tickets[stream];
+	graph_note_needs(ctx, stream, g);
 	VP_CHECK_HIP(hipGraphLaunch(g->exec, s)); // (the capture counted this launch's SAT tickets already)
+	ctx->graph_stats[0]++;
+	return VP_OK;
+}
+
+// captures made, replays launched, captures refused, graphs dropped because the stream's state had moved -- since the context was created
+extern "C" int vp_frame_graph_stats(VpContext* ctx, int64_t out[4]) {
+	VP_REQUIRE(ctx && out, "vp_frame_graph_stats: bad arguments");
+	for(int i = 0; i < 4; i++) out[i] = ctx->graph_stats[i];
 	return VP_OK;
 }
 
@@ -155,6 +210,8 @@ static int frame_body(VpContext* ctx, int stream, const VpFrameParams* p, const 
 		bool grew = false;
 		VP_TRY(vp_workspace(ctx, stream, 2, sizeof(float) * 2 * (size_t)p->fw * p->fh, &map, &grew));
 		if(grew || memcmp(key, ctx->map_key[stream], sizeof(key)) != 0) {
+			// a map built inside a capture would be rebuilt by every replay, and a discarded capture would leave map_key claiming a map that was never built
+			VP_REQUIRE(!ctx->capturing[stream], "the coordinate map would have to be rebuilt inside a graph capture");
 			VP_TRY(vp_resample_map(ctx, stream, &p->model, p->max_robot_height, p->field_scale, p->off_x, p->off_y, p->fw, p->fh, static_cast<float*>(map)));
 			memcpy(ctx->map_key[stream], key, sizeof(key));
 		}

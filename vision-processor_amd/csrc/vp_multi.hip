@@ -9,6 +9,7 @@
 
 struct VpGather {
 	int n = 0, slots = 0;
+	bool loopback = false;                        // vp_gather_create_loopback: every rank on ONE device, device-to-device copies instead of RCCL (tests only)
 	size_t bytes = 0;
 	std::vector<int> dev;
 	std::vector<ncclComm_t> comm;
@@ -69,7 +70,7 @@ static int gather_init(VpGather* g) {
 	}
 	for(int r = 0; r < g->n; r++) {
 		VP_REQUIRE(g->dev[r] >= 0 && g->dev[r] < have, "vp_gather_create: device %d out of range [0,%d)", g->dev[r], have);
-		for(int q = 0; q < r; q++) VP_REQUIRE(g->dev[q] != g->dev[r], "vp_gather_create: device %d listed twice", g->dev[r]);
+		for(int q = 0; q < r && !g->loopback; q++) VP_REQUIRE(g->dev[q] != g->dev[r], "vp_gather_create: device %d listed twice", g->dev[r]);
 	}
 	g->gs.assign(g->n, nullptr);
 	g->comm.assign(g->n, nullptr);
@@ -91,16 +92,16 @@ static int gather_init(VpGather* g) {
 			VP_CHECK_HIP(hipEventCreateWithFlags(&g->done[r][s], hipEventDisableTiming));
 		}
 	}
-	VP_CHECK_NCCL(ncclCommInitAll(g->comm.data(), g->n, g->dev.data()));
+	if(!g->loopback) VP_CHECK_NCCL(ncclCommInitAll(g->comm.data(), g->n, g->dev.data()));
 	return VP_OK;
 }
 
-extern "C" int vp_gather_create(int n_devices, const int* devices, size_t bytes_per_device, int n_slots, VpGather** out) {
-	VP_REQUIRE(out && devices && n_devices >= 1 && n_devices <= 64 && bytes_per_device > 0 && n_slots >= 1 && n_slots <= 4, "vp_gather_create: bad arguments");
+static int gather_create(int n_devices, const int* devices, size_t bytes_per_device, int n_slots, bool loopback, VpGather** out) {
 	VpGather* g = new VpGather();
 	g->n = n_devices;
 	g->slots = n_slots;
 	g->bytes = bytes_per_device;
+	g->loopback = loopback;
 	g->dev.assign(devices, devices + n_devices);
 	const int rc = gather_init(g);
 	if(rc != VP_OK) {
@@ -110,6 +111,21 @@ extern "C" int vp_gather_create(int n_devices, const int* devices, size_t bytes_
 	*out = g;
 	return VP_OK;
 }
+
+extern "C" int vp_gather_create(int n_devices, const int* devices, size_t bytes_per_device, int n_slots, VpGather** out) {
+	VP_REQUIRE(out && devices && n_devices >= 1 && n_devices <= 64 && bytes_per_device > 0 && n_slots >= 1 && n_slots <= 4, "vp_gather_create: bad arguments");
+	return gather_create(n_devices, devices, bytes_per_device, n_slots, false, out);
+}
+
+// Test-only: n ranks that all live on ONE device.  Never chosen implicitly and never a fallback of vp_gather_create; exists so that the N > 1 host
+// pipeline (driver threads, rendezvous, slot reuse, end-of-run drain of host/feeds_multi.cpp) can execute on a one-GPU box.
+extern "C" int vp_gather_create_loopback(int n_ranks, int device, size_t bytes_per_rank, int n_slots, VpGather** out) {
+	VP_REQUIRE(out && n_ranks >= 1 && n_ranks <= 64 && bytes_per_rank > 0 && n_slots >= 1 && n_slots <= 4, "vp_gather_create_loopback: bad arguments");
+	const std::vector<int> devs(n_ranks, device);
+	return gather_create(n_ranks, devs.data(), bytes_per_rank, n_slots, true, out);
+}
+
+extern "C" int vp_gather_is_loopback(const VpGather* g) { return g && g->loopback ? 1 : 0; }
 
 extern "C" int vp_gather_devices(const VpGather* g) { return g ? g->n : 0; }
 extern "C" void* vp_gather_send(VpGather* g, int rank, int slot) { return (g && rank >= 0 && rank < g->n && slot >= 0 && slot < g->slots) ? g->send[rank][slot] : nullptr; }
@@ -123,6 +139,18 @@ extern "C" int vp_gather_start(VpGather* g, int slot, VpContext* const* ctx, con
 		VP_CHECK_HIP(hipSetDevice(g->dev[r]));
 		VP_CHECK_HIP(hipEventRecord(g->ready[r][slot], ctx[r]->streams[stream[r]]));
 		VP_CHECK_HIP(hipStreamWaitEvent(g->gs[r], g->ready[r][slot], 0));
+	}
+	if(g->loopback) { // the all-gather as n x n device-to-device copies: receiver r's gather stream waits for EVERY owner's stream, then copies every block
+		VP_CHECK_HIP(hipSetDevice(g->dev[0]));
+		for(int r = 0; r < g->n; r++) {
+			for(int q = 0; q < g->n; q++) {
+				if(q != r) VP_CHECK_HIP(hipStreamWaitEvent(g->gs[r], g->ready[q][slot], 0));
+				VP_CHECK_HIP(hipMemcpyAsync(static_cast<uint8_t*>(g->recv[r][slot]) + (size_t)q * g->bytes, g->send[q][slot], g->bytes, hipMemcpyDeviceToDevice, g->gs[r]));
+			}
+			VP_CHECK_HIP(hipEventRecord(g->done[r][slot], g->gs[r]));
+		}
+		g->started[slot] = 1;
+		return VP_OK;
 	}
 	VP_CHECK_NCCL(ncclGroupStart());
 	for(int r = 0; r < g->n; r++) {

@@ -707,13 +707,13 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	// launches to restart before the 32-bit ticket counters (and the 30-bit epochs) wrap.
 	const uint64_t shape = ((uint64_t)a.tilesX << 44) | ((uint64_t)a.tilesY << 24) | (uint64_t)batch;
 	const bool reshaped = ctx->sat_shape[stream] != shape || ctx->sat_tickets[stream] != a.tickets_per_launch;
-	ctx->sat_shape[stream] = shape;
-	ctx->sat_tickets[stream] = a.tickets_per_launch;
 	const bool reset = grew || poisoned || reshaped || ctx->sat_epoch[stream] >= (1u << 30) - 2 || ((uint64_t)ctx->sat_epoch[stream] + 2) * a.tickets_per_launch >= (uint64_t(1) << 32);
 	if(reset && ctx->capturing[stream]) {
-		vp_set_error("the single-pass SAT state would have to be reset inside a graph capture");
+		vp_set_error("the single-pass SAT state would have to be reset inside a graph capture"); // refused before any host state changes
 		return VP_ERR_INVALID;
 	}
+	ctx->sat_shape[stream] = shape;
+	ctx->sat_tickets[stream] = a.tickets_per_launch;
 	if(reset) {
 		if(!grew) {
 			VP_CHECK_HIP(hipStreamSynchronize(s));

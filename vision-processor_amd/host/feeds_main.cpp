@@ -7,7 +7,9 @@
 //        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--detect] [--threads T=16] [--cap C=192] [--full-records] [--local] [--verify] [--dump FILE]
 //            feeds_multi.cpp: N devices, one driver thread each, one RCCL all-gather per step of the encoded SSL_WrapperPackets (--detect: the CPU stage
 //            runs per device on T / N host threads) or of the compact blob records (--cap records per feed; --full-records: the fixed-capacity arrays
-//            as vp_frame writes them); --local = VP_SAT_LOCAL; --verify: every device received every owner's block; --dump: the last device's receive area
+//            as vp_frame writes them); --local = VP_SAT_LOCAL; --verify: every device received every owner's block; --dump: the last device's receive area;
+//            --same-device (TEST-ONLY): all N ranks on device 0 with a loop-back gather (device-to-device copies, no RCCL) so that the N > 1 pipeline
+//            -- driver threads, rendezvous, last-arriver gather, slot reuse, drain -- can run on a one-GPU box
 // Scene and geometry: SURVEY.md 8(d) cfg2 (2048x1536 RGGB, nadir camera 5 m over a 9.6 x 7.2 m patch, 16 robots, 8 balls per feed).
 #include <chrono>
 #include <cmath>
@@ -18,6 +20,7 @@
 
 #include "vp_hip.h"
 #include "vp_host.h"
+#include "feeds.h"
 
 #define CK(call) \
 	do { \
@@ -28,12 +31,6 @@
 		} \
 	} while(0)
 
-struct MultiOptions { // feeds_multi.cpp
-	int gpus = 1, feeds = 128, steps = 20, warmup = 3;
-	int verify = 0, local = 0, detect = 0, threads = 16, cap = 192, full = 0;
-	const char* dump = nullptr;
-};
-int vp_feeds_run_multi(const MultiOptions& o);
 
 // cfg2: kernel scalars assigned directly
 void vp_feeds_cfg2_params(VpFrameParams* out) {
@@ -73,6 +70,7 @@ int main(int argc, char** argv) {
 		for(int i = 3; i < argc; i++) {
 			if(strcmp(argv[i], "--verify") == 0) o.verify = 1;
 			else if(strcmp(argv[i], "--local") == 0) o.local = 1;
+			else if(strcmp(argv[i], "--same-device") == 0) o.same_device = 1;
 			else if(strcmp(argv[i], "--detect") == 0) o.detect = 1;
 			else if(strcmp(argv[i], "--full-records") == 0) o.full = 1;
 			else if(strcmp(argv[i], "--threads") == 0 && i + 1 < argc) o.threads = atoi(argv[++i]);
@@ -85,7 +83,7 @@ int main(int argc, char** argv) {
 		o.steps = pos[1];
 		o.warmup = pos[2];
 		if(np > 3 || o.feeds < 1 || o.steps < 1 || o.warmup < 0 || o.threads < 1 || o.cap < 1) {
-			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--detect] [--threads T] [--cap C] [--full-records] [--local] [--verify] [--dump FILE]\n");
+			fprintf(stderr, "usage: vp_feeds --gpus N [feeds per GPU] [steps] [warmup] [--detect] [--threads T] [--cap C] [--full-records] [--local] [--verify] [--dump FILE] [--same-device]\n");
 			return 2;
 		}
 		return vp_feeds_run_multi(o);

@@ -8,6 +8,7 @@
 // device's block -- the encoded SSL_WrapperPackets with --detect, the compact blob records without -- on the gather streams, beside the next step's
 // kernels.  This replaces the reference's per-camera processes (one loop per camera, src/main.cpp:262-317; hypotheses -> SSL_WrapperPacket,
 // main.cpp:319-370) exchanging packets over UDP multicast (src/udpsocket.cpp:94-100 send, :147-163 receive).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -21,6 +22,7 @@
 #include "vp_hip.h"
 #include "vp_host.h"
 #include "vp_multi.h"
+#include "feeds.h"
 
 #define CK(call) \
 	do { \
@@ -31,13 +33,6 @@
 		} \
 	} while(0)
 
-void vp_feeds_cfg2_params(VpFrameParams* p); // feeds_main.cpp
-
-struct MultiOptions {
-	int gpus = 1, feeds = 128, steps = 20, warmup = 3;
-	int verify = 0, local = 0, detect = 0, threads = 16, cap = 192, full = 0;
-	const char* dump = nullptr;
-};
 
 namespace {
 
@@ -73,7 +68,9 @@ struct Dev {
 	void* hSlots[2] = {nullptr, nullptr};
 	void* hPackets[2] = {nullptr, nullptr};
 	std::vector<VphDetector*> det;
-	long blobs = 0, packetBytes = 0, robots = 0, balls = 0;
+	uint8_t* dSlotsFull = nullptr; // a frame with more blobs than --cap: the step's records once more with cap = maxBlobs (allocated on first use)
+	void* hSlotsFull = nullptr;
+	long blobs = 0, packetBytes = 0, robots = 0, balls = 0, overflowSteps = 0;
 	double stageMs = 0, waitMs = 0;
 	VpPlacement place[2];
 };
@@ -82,7 +79,7 @@ struct Dev {
 
 int vp_feeds_run_multi(const MultiOptions& o) {
 	const int visible = vp_device_count();
-	if(o.gpus < 1 || o.gpus > visible) {
+	if(o.gpus < 1 || visible < 1 || (o.gpus > visible && !o.same_device)) {
 		fprintf(stderr, "[FATAL] --gpus %d but %d HIP device(s) are visible\n", o.gpus, visible);
 		return 1;
 	}
@@ -95,14 +92,17 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 	size_t offC = 0, offM = 0, offI = 0, slotBytes = 0;
 	const size_t fullBytes = vp_record_layout(feeds, mm, &offC, &offM, &offI);
 	const size_t compactBytes = vp_record_layout_compact(feeds, o.cap, &slotBytes, nullptr, nullptr);
+	size_t fullSlotBytes = 0;
+	const size_t fullSlotBlock = vp_record_layout_compact(feeds, mm, &fullSlotBytes, nullptr, nullptr); // the overflow path of --detect
 	const size_t packetBytes = vp_packet_layout(feeds, packetSlot);
 	const size_t blockBytes = o.detect ? packetBytes : (o.full ? fullBytes : compactBytes);
 	const char* blockKind = o.detect ? "SSL_WrapperPacket slots" : (o.full ? "full records" : "compact records");
 
 	std::vector<int> devs(N);
-	for(int g = 0; g < N; g++) devs[g] = g;
+	for(int g = 0; g < N; g++) devs[g] = o.same_device ? 0 : g;
 	VpGather* gather = nullptr;
-	CK(vp_gather_create(N, devs.data(), blockBytes, 2, &gather));
+	if(o.same_device) CK(vp_gather_create_loopback(N, 0, blockBytes, 2, &gather)); // test-only: N ranks on device 0, asked for by name, never a fallback
+	else CK(vp_gather_create(N, devs.data(), blockBytes, 2, &gather));
 	std::vector<Dev> dev(N);
 	std::vector<VpContext*> ctxs(N, nullptr);
 	const int threadsPerDev = std::max(1, o.threads / N);
@@ -116,7 +116,7 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 			th.emplace_back([&, g] {
 				Dev& d = dev[g];
 				d.g = g;
-				CK(vp_ctx_create(g, 2, &d.ctx));
+				CK(vp_ctx_create(devs[g], 2, &d.ctx));
 				ctxs[g] = d.ctx;
 				CK(vp_malloc_device(d.ctx, rawBytes * feeds, (void**)&d.dRaw));
 				std::vector<uint8_t> frame(rawBytes);
@@ -194,10 +194,31 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 			const auto w1 = now();
 			const uint32_t frameNo = (uint32_t)k + 1; // steps are numbered from 1
 			const double t = frameNo / 70.0;
-			const int rc = vph_detect_batch_slots(d.det.data(), feeds, static_cast<const uint8_t*>(d.hSlots[s]), slotBytes, mm, frameNo, t, t, t + 0.002, threadsPerDev,
-					static_cast<uint8_t*>(d.hPackets[s]), packetSlot);
+			// The reference reads min(counter[0], maxBlobs) records (main.cpp:301); a compact slot holds at most --cap of them.  A step in which some
+			// feed has more is read once more at full capacity (buf[s] still holds step k: the next launch into it is step k + 2) -- nothing is dropped.
+			const uint8_t* slots = static_cast<const uint8_t*>(d.hSlots[s]);
+			size_t stride = slotBytes;
+			bool overflow = false;
+			for(int i = 0; i < feeds && !overflow; i++) {
+				int32_t head[4];
+				memcpy(head, slots + (size_t)i * slotBytes, sizeof(head));
+				overflow = head[3] < std::min(std::max(head[0], 0), mm);
+			}
+			if(overflow) {
+				if(!d.dSlotsFull) {
+					CK(vp_malloc_device(d.ctx, fullSlotBlock, (void**)&d.dSlotsFull));
+					CK(vp_malloc_host(d.ctx, fullSlotBlock, &d.hSlotsFull));
+				}
+				CK(vp_records_compact(d.ctx, s, d.buf[s].counter, d.buf[s].matches, nullptr, feeds, mm, mm, d.dSlotsFull));
+				CK(vp_copy_d2h(d.ctx, s, d.hSlotsFull, d.dSlotsFull, fullSlotBlock));
+				CK(vp_sync(d.ctx, s));
+				slots = static_cast<const uint8_t*>(d.hSlotsFull);
+				stride = fullSlotBytes;
+				d.overflowSteps++;
+			}
+			const int rc = vph_detect_batch_slots(d.det.data(), feeds, slots, stride, mm, frameNo, t, t, t + 0.002, threadsPerDev, static_cast<uint8_t*>(d.hPackets[s]), packetSlot);
 			if(rc != VP_OK) {
-				fprintf(stderr, "[FATAL] device %d step %d: the CPU stage refused the record slots (a frame has more than --cap %d blobs?)\n", g, k, o.cap);
+				fprintf(stderr, "[FATAL] device %d step %d: the CPU stage refused the record slots: %s\n", g, k, vp_last_error());
 				exit(1);
 			}
 			CK(vp_gather_wait(gather, s)); // the gather issued two steps ago has released this slot's block
@@ -207,7 +228,7 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 				d.stageMs += ms(w1, now());
 				for(int i = 0; i < feeds; i++) {
 					int32_t head[4], len;
-					memcpy(head, static_cast<const uint8_t*>(d.hSlots[s]) + (size_t)i * slotBytes, sizeof(head));
+					memcpy(head, slots + (size_t)i * stride, sizeof(head));
 					memcpy(&len, static_cast<const uint8_t*>(d.hPackets[s]) + (size_t)i * packetSlot, 4);
 					d.blobs += head[3];
 					d.packetBytes += len > 0 ? len : 0;
@@ -278,10 +299,12 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 
 	long blobs = 0;
 	printf("{\"program\": \"vp_feeds\", \"gpus\": %d, \"feeds_per_gpu\": %d, \"steps\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"record_bytes_per_gpu\": %zu, \"block\": \"%s\", "
-		   "\"full_record_bytes_per_gpu\": %zu, \"gather\": \"RCCL ncclAllGather, one grouped call per step, %d rank(s) in one process, one driver thread per device\", \"sat_variant\": \"%s\"",
-			N, feeds, o.steps, (double)N * feeds * o.steps / dt, 1e3 * dt / o.steps, blockBytes, blockKind, fullBytes, N, o.local ? "local" : "tiled");
+		   "\"full_record_bytes_per_gpu\": %zu, \"gather\": \"%s, one grouped call per step, %d rank(s) in one process, one driver thread per device\", \"same_device\": %s, \"sat_variant\": \"%s\"",
+			N, feeds, o.steps, (double)N * feeds * o.steps / dt, 1e3 * dt / o.steps, blockBytes, blockKind, fullBytes,
+			vp_gather_is_loopback(gather) ? "TEST-ONLY loop-back (all ranks on device 0, device-to-device copies, no RCCL)" : "RCCL ncclAllGather", N, o.same_device ? "true" : "false",
+			o.local ? "local" : "tiled");
 	if(o.detect) {
-		long robots = 0, balls = 0, pbytes = 0;
+		long robots = 0, balls = 0, pbytes = 0, overflowSteps = 0;
 		double stage = 0, wait = 0;
 		for(Dev& d : dev) {
 			for(VphDetector* dt2 : d.det) {
@@ -291,15 +314,17 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 				balls += h.n_balls;
 			}
 			blobs += d.blobs;
+			overflowSteps += d.overflowSteps;
 			pbytes += d.packetBytes;
 			stage += d.stageMs;
 			wait += d.waitMs;
 		}
 		printf(", \"detect\": {\"host_threads_per_gpu\": %d, \"robots_per_frame\": %.3f, \"balls_per_frame\": %.3f, \"packet_bytes_per_frame\": %.1f, \"packet_slot_bytes\": %d, "
-			   "\"host_ms_per_step\": {\"wait_for_gpu\": %.3f, \"cpu_stage\": %.3f}, \"rendered\": {\"robots\": 16, \"balls\": 8}}, \"blobs_per_frame\": %.2f",
+			   "\"host_ms_per_step\": {\"wait_for_gpu\": %.3f, \"cpu_stage\": %.3f}, \"steps_reread_at_full_capacity\": %ld, \"rendered\": {\"robots\": 16, \"balls\": 8}}, \"blobs_per_frame\": %.2f",
 				threadsPerDev, robots / ((double)N * feeds), balls / ((double)N * feeds), pbytes / ((double)N * feeds * o.steps), packetSlot, wait / N / o.steps, stage / N / o.steps,
-				blobs / ((double)N * feeds * o.steps));
+				overflowSteps, blobs / ((double)N * feeds * o.steps));
 	} else {
+		long truncated = 0; // compact slots of the LAST step that hold fewer records than min(counter[0], maxBlobs): --cap too small for that frame
 		printf(", \"counters\": [");
 		for(int g = 0; g < N; g++) {
 			printf("%s[", g ? ", " : "");
@@ -309,10 +334,12 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 				else memcpy(c, own.data() + (size_t)g * blockBytes + (size_t)i * slotBytes, 16);
 				printf("%s[%d, %d, %d]", i ? ", " : "", c[0], c[1], c[2]);
 				blobs += c[0] < mm ? c[0] : mm;
+				if(!o.full && c[3] < std::min(std::max(c[0], 0), mm)) truncated++;
 			}
 			printf("]");
 		}
-		printf("], \"blobs_per_frame\": %.2f", blobs / ((double)N * feeds));
+		printf("], \"blobs_per_frame\": %.2f, \"truncated_slots_last_step\": %ld", blobs / ((double)N * feeds), truncated);
+		if(truncated) fprintf(stderr, "[WARN] %ld compact record slot(s) of the last step hold fewer records than the host loop reads (main.cpp:301): raise --cap (%d)\n", truncated, o.cap);
 	}
 	printf(", \"placement\": {\"sat_write_gbs\": [");
 	for(int g = 0; g < N; g++) printf("%s%.0f", g ? ", " : "", dev[g].place[0].write_gbs);
@@ -327,6 +354,8 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 		for(int s = 0; s < 2; s++) {
 			vp_frame_buffers_destroy(d.ctx, d.slab[s]);
 			if(d.dSlots[s]) vp_free_device(d.ctx, d.dSlots[s]);
+			if(s == 0 && d.dSlotsFull) vp_free_device(d.ctx, d.dSlotsFull);
+			if(s == 0 && d.hSlotsFull) vp_free_host(d.ctx, d.hSlotsFull);
 			if(d.hSlots[s]) vp_free_host(d.ctx, d.hSlots[s]);
 			if(d.hPackets[s]) vp_free_host(d.ctx, d.hPackets[s]);
 		}
