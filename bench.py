@@ -263,9 +263,57 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
             gstreams[f"{ns}x{b}"] = round(rate(go, 100 if b == 1 else 30, ns * b), 1)
         out["frames_per_s_streams_x_frames_per_launch_frame_graph"] = gstreams
         ctx.tune("frame_graph", 0)
+        out["cfg5_sat_variants"] = cfg5_sat_variants(capi, torch, np, ctx)
         out["note"] = "measured after the timed region on the same resident frames (PCIe figure: host-pinned frames copied in, records copied out); none of these is `value`"
     finally:
         ctx.close()
+    return out
+
+
+def cfg5_sat_variants(capi, torch, np, ctx, B=32):
+    """BASELINE configs[4]: the 4096x3072 feed, LDS-tiled single-pass SAT against the global-recursive (row pass + column pass) variant, as HBM
+    bandwidth of the gradientDot+SAT pass on its algorithmic 8 B per flat pixel.  32 frames per launch (4 distinct rendered frames, repeated), buffers from
+    vp_frame_buffers_create; hipEvents around the stage on the launch stream; one frame of each variant's last launch held to the CPU oracle."""
+    from _vp_pkg import load
+    from concurrent.futures import ThreadPoolExecutor
+    vp = load()
+    cfg = vp.configs.CFG5
+    mm = cfg.max_matches
+    with ThreadPoolExecutor(4) as pool:
+        distinct = list(pool.map(lambda i: cfg.synth(vp.feeds.feed_seed(5, i)), range(4)))
+    raws = np.stack([distinct[i % 4] for i in range(B)])
+    d_raw = torch.from_numpy(raws).cuda()
+    out = {"workload": cfg.name, "frames_per_launch": B, "algorithmic_bytes_per_launch": 8.0 * cfg.n_flat * B, "peak_gbs": HBM_PEAK_GBS}
+    for name, sv in (("tiled", capi.SAT_TILED), ("twopass", capi.SAT_TWOPASS)):
+        p = capi.frame_params(cfg, sat_variant=sv, order=capi.ORDER_RASTER)
+        slab = ctx.frame_slab(p, B)
+        try:
+            for _ in range(3):
+                ctx.frame_buffers(p, d_raw, B, slab.b)
+            ctx.sync()
+            ctx.events_clear()
+            ctx.events_enable(True)
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                ctx.frame_buffers(p, d_raw, B, slab.b)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            ctx.events_enable(False)
+            st = {}
+            for tag, ms in ctx.event_times():
+                st.setdefault(tag, []).append(ms)
+            ctx.events_clear()
+            ms = float(np.mean(st["gradientDot+sat"]))
+            gbs = 8.0 * cfg.n_flat * B / (ms * 1e-3) / 1e9
+            flat, sat, m_t, idx_t, cnt_t = slab.torch_views()
+            ver = verify_against_oracle(cfg, raws, [B - 1], flat, sat, m_t, idx_t, cnt_t, mm)
+            del flat, sat, m_t, idx_t, cnt_t
+            out[name] = {"launch_ms": round(ms, 4), "achieved_gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "frames_per_s_whole_path": round(B * n / dt, 1),
+                         "stage_ms": {k: round(float(np.mean(v)), 4) for k, v in st.items()}, "verified": ver["ok"], "mismatches": ver["mismatches"],
+                         "sat_block_write_gbs": slab.placement["sat"]["write_gbs"]}
+        finally:
+            slab.destroy()
     return out
 
 
@@ -361,11 +409,12 @@ def verify_against_oracle(cfg, raws, frames, flat, sat, matches, idx, counter, m
 
 
 def cpu_baseline(cfg, seconds, opencl):
-    """The CPU checkers timed on the host cores, never part of the measured GPU path.  kind "reference" (when oracle/_ref is present) =
-    the reference's kernel/*.cl compiled unmodified for x86, linked against oracle/ref_shim.c -- this repo's stand-in for the OpenCL
-    builtin library (work-item ids, image reads / writes, samplers), since no OpenCL runtime that could run them exists here (see
-    `opencl`).  The kernel arithmetic is the reference's compiled code, the image semantics are this repo's reading of the spec.
-    Nested `port` = this repo's plain-C restatement (oracle/vp_oracle.c) on the same cores."""
+    """The CPU checkers timed on the host cores, never part of the measured GPU path.  kind "port" = this repo's plain-C restatement
+    (oracle/vp_oracle.c), the faster of the two and the one no rule questions.  Nested `reference_kernels_with_builtin_shim` (when oracle/_ref
+    is present) = the reference's kernel/*.cl compiled unmodified for x86 but linked against oracle/ref_shim.c -- this repo's stand-in for
+    the OpenCL builtin library (work-item ids, image reads / writes, samplers), since no OpenCL runtime that could run them exists here (see
+    `opencl`): the kernel arithmetic is the reference's compiled code, the image semantics are this repo's reading of the spec, so it is
+    NOT "the reference run here" and is reported for information only."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -406,11 +455,11 @@ def cpu_baseline(cfg, seconds, opencl):
         t1 = time.perf_counter()
         ref_one(0, 1)
         single = 1.0 / (time.perf_counter() - t1)
-        port_out = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
-        out = {"value": round(rn / rdt, 3), "unit": "frames/s", "cores": cores, "kind": "reference", "opencl_runtimes": out["opencl_runtimes"],
-               "sample": f"{rn} frames of {cfg.name} through the reference's kernel/*.cl compiled unmodified for x86 (oracle/_ref) and linked against oracle/ref_shim.c, "
-                         f"this repo's stand-in for the OpenCL builtin library (NOT a real OpenCL runtime: none that can run image kernels exists on this box); "
-                         f"each NDRange in row bands over {cores} host threads, {rdt:.1f} s; one thread: {single:.3f} frames/s", "port": port_out}
+        out["reference_kernels_with_builtin_shim"] = {
+            "value": round(rn / rdt, 3), "unit": "frames/s", "cores": cores,
+            "sample": f"{rn} frames of {cfg.name} through the reference's kernel/*.cl compiled unmodified for x86 (oracle/_ref) and linked against oracle/ref_shim.c, "
+                      f"this repo's stand-in for the OpenCL builtin library (NOT a real OpenCL runtime: none that can run image kernels exists on this box); "
+                      f"each NDRange in row bands over {cores} host threads, {rdt:.1f} s; one thread: {single:.3f} frames/s"}
     return out
 
 
@@ -643,6 +692,11 @@ def main():
         # written (resampling), flat read + table written (SAT pass), table read (circle + blobList), flat read (local variant)
         per_px = {"raw2quad+resampling": 4.0 + cfg.qw * cfg.qh * (3.0 if cfg.layout == vp.configs.BGR else 4.0) / cfg.n_flat, "gradientDot+sat": 8.0, "satBlobCenter+blobList": 4.0,
                   "gradientDot+satBlobCenter+blobList (local)": 4.0}
+        # the whole path on its compulsory bytes: raw sensor in + flat out / in + table out / in (no table with --sat local: raw + flat out / in)
+        path_bytes = cfg.raw_bytes + (8.0 if args.sat == "local" else 16.0) * cfg.n_flat
+        path_gbs = path_bytes * B * args.steps / elapsed / 1e9  # per GPU: every rank runs B frames per step
+        out["path_roofline"] = {"bound": "hbm", "bytes_per_frame": path_bytes, "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(path_gbs / HBM_PEAK_GBS, 4),
+                                "note": "compulsory bytes of one frame x frames per step / ms_per_step of this rank's GPU (whole hot path, all launches and gaps included)"}
         out["stage_roofline_frac"] = {k: round(per_px[k] * cfg.n_flat * B / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in stage_ms.items() if k in per_px}
         if dist and det is None:
             # what the last step gathered: rank 0's own slots must be what vp_frame left in its arrays, and no slot may have been too small

@@ -161,3 +161,68 @@ def test_frame_graph_alternating_launch_shapes_on_one_stream(env, port, variant,
         assert stats["captures"] >= 2 and stats["replays"] >= 2 and stats["dropped"] >= 2 and (stats["refused"] >= 3 if mode == 2 else stats["refused"] == 0), stats
     finally:
         ctx.close()
+
+
+# ---- BASELINE configs[4] at the launch profiles/ quotes: 4096x3072 x 32 frames, LDS-tiled vs global-recursive SAT -------------------------------------
+CFG5 = cfgs.CFG5
+B5 = 32
+ORACLE5 = (0, 15, 16, 31)
+
+
+def test_config4_high_res_launch_tiled_twopass_local_against_the_oracle(env):
+    """cfg5 (4096x3072 RGGB, o = 3, r = 9, R = 8) x 32 frames through vp_frame_buffers_create, the launch the tiled-vs-global-recursive comparison of
+    BASELINE configs[4] is quoted on (bench.py extras.cfg5_sat_variants, profiles/): VP_SAT_TILED, VP_SAT_TWOPASS and VP_SAT_LOCAL.  Frames 0, 15, 16, 31
+    byte for byte against the CPU oracle (flat, int32 SAT, counters, raster-sorted records); all 32 through the size-independent property SAT == 64-bit
+    cumulative sums of gradientDot of the kernel's own flat in plain torch integer arithmetic; the three variants' records equal each other on all 32.
+    Replaces satHorizontal.cl:22-32 + satVertical.cl:22-32 at the size SURVEY section 5 "long-context" names."""
+    from concurrent.futures import ThreadPoolExecutor
+    from test_gpu_round3 import torch_sat_reference
+    capi, torch = env
+    cfg, B, mm = CFG5, B5, CFG5.max_matches
+    with ThreadPoolExecutor(16) as ex:
+        raws = np.stack(list(ex.map(cfg.synth, [cases.vp.feeds.feed_seed(5, i) for i in range(B)])))
+    big = O.Port(threads=min(16, os.cpu_count() or 1))
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    want = {}
+    for k in ORACLE5:
+        s = big.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+        m, idx, cnt = big.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                                cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+        sat, mx = big.sat_i32(s["graddot"])
+        assert mx < 2 ** 24 and len(m) >= 80
+        want[k] = dict(flat=s["flat"].copy(), sat=sat, m=m, idx=idx, cnt=cnt)
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        d_raw = dev(torch, raws)
+        results = {}
+        for name, sv in (("tiled", capi.SAT_TILED), ("twopass", capi.SAT_TWOPASS), ("local", capi.SAT_LOCAL)):
+            p = capi.frame_params(cfg, sat_variant=sv, order=capi.ORDER_RASTER)
+            slab = ctx.frame_slab(p, B)
+            for _ in range(2):
+                ctx.frame_buffers(p, d_raw, B, slab.b)
+            ctx.sync()
+            flat, sat, m_t, idx_t, cnt_t = slab.torch_views()
+            cnt = cnt_t.cpu().numpy()
+            for k in ORACLE5:
+                w_ = want[k]
+                assert torch.equal(flat[k].cpu(), torch.from_numpy(w_["flat"])), (name, k, "flat")
+                if sat is not None:
+                    assert torch.equal(sat[k].cpu(), torch.from_numpy(w_["sat"])), (name, k, "sat")
+                assert np.array_equal(cnt[k], w_["cnt"]), (name, k, cnt[k], w_["cnt"])
+                n = min(int(cnt[k, 0]), mm)
+                assert np.array_equal(idx_t[k].cpu().numpy().view(np.uint32)[:n], w_["idx"]) and m_t[k].cpu().numpy()[:22 * n].tobytes() == w_["m"].tobytes(), (name, k, "records")
+            if sat is not None:
+                for k0 in range(0, B, 4):
+                    assert torch.equal(sat[k0:k0 + 4], torch_sat_reference(torch, flat[k0:k0 + 4], cfg.grad_offset)), (name, "SAT property", k0)
+            results[name] = (cnt.copy(), m_t.cpu().numpy().copy(), idx_t.cpu().numpy().copy())
+            del flat, sat, m_t, idx_t, cnt_t
+            slab.destroy()
+        ct, mt, it = results["tiled"]
+        for name in ("twopass", "local"):
+            c2, m2, i2 = results[name]
+            assert np.array_equal(c2, ct), name
+            for k in range(B):
+                n = min(int(ct[k, 0]), mm)
+                assert np.array_equal(i2[k, :n], it[k, :n]) and m2[k, :22 * n].tobytes() == mt[k, :22 * n].tobytes(), (name, k)
+    finally:
+        ctx.close()
