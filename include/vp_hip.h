@@ -95,7 +95,8 @@ const char* vp_device_name(VpContext* ctx);
 /* Result-neutral tuning (every value gives bit-identical output; the library reads no environment variable):
  *   "sat_workgroups_per_cu" 2..8 (0 = automatic, the default), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_float_stage" 0 / 1 (default 1),
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
- *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
+ *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "tail_emit_kernel" 0 / 1 (default 1: the walkers' survivors become records in a second
+ *   launch, one workgroup per frame; 0: inside the walker), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
  *   write the dense halo strips the tiled SAT pass reads), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
  *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 / 2 (default 0; 1: vp_frame captures the launches of a (stream, parameters, batch,
  *   buffers) call into a hipGraph when the call follows itself on the stream and replays the graph from then on; a stream whose state belongs to another

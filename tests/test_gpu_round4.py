@@ -226,3 +226,71 @@ def test_config4_high_res_launch_tiled_twopass_local_against_the_oracle(env):
                 assert np.array_equal(i2[k, :n], it[k, :n]) and m2[k, :22 * n].tobytes() == mt[k, :22 * n].tobytes(), (name, k)
     finally:
         ctx.close()
+
+
+# ---- the walkers' survivor queues: records inside the walker, by the second launch, and every overflow path between them -------------------------------
+@pytest.mark.parametrize("emit_kernel,cand_cap", [(0, 0), (1, 0), (1, 64), (1, 8), (1, 7)])
+@pytest.mark.parametrize("walker", ["table", "local"])
+def test_walker_survivor_queue_paths(env, port, walker, emit_kernel, cand_cap):
+    """k_circle_walk / k_flat_walk queue their survivors in LDS and make records after the row loop: inside the walker (tail_emit_kernel 0) or, through
+    the frames' queues in global memory, by k_emit_queue (1).  Inputs that push every limit: a frame in which EVERY pixel is a plateau peak (a wavefront
+    finds 58 survivors per row: the LDS queue stops the walk after every row and the wavefront walks again from the next one; the frame's queue --
+    candidate_capacity / 8 entries: default, 8, 1 and 0 -- overflows and the rest is drained inside the walker; counter[0] runs far past max_matches),
+    the same frame beside ordinary ones in one launch, and noise with many rings.  Counters, blob sets and (RASTER) order equal the oracle's
+    gradientDot -> SAT -> circle -> matches.  blobList.cl:36-103, main.cpp:283-317."""
+    capi, torch = env
+    rng = np.random.default_rng(4242)
+    h, w, B = 150, 200, 4
+    o, r, R = (2, 5, 4)
+    flat = np.zeros((B, h, w, 4), np.uint8)
+    flat[..., 3] = 255
+    flat[0, ..., :3] = (90, 90, 90)                                  # constant: gradDot == 0, every pixel a plateau peak at threshold 0
+    flat[1, ..., :3] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)  # noise
+    flat[2, ..., :3] = (100, 140, 120)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(60):                                              # many small discs, some clustered in one 52-column strip
+        cy, cx = int(rng.integers(0, h)), int(rng.integers(20, 70))
+        flat[2, (yy - cy) ** 2 + (xx - cx) ** 2 <= 16, :3] = rng.integers(0, 256, 3, dtype=np.uint8)
+    flat[3] = flat[0]
+    flat[3, 40:90, 50:150, :3] = rng.integers(80, 100, (50, 100, 3), dtype=np.uint8)
+    for thr, mm in ((0.0, 50), (0.0, 40000), (15.0, 2000)):
+        want = []
+        for i in range(B):
+            gd = port.graddot(flat[i], o)
+            sat, _ = port.sat_i32(gd)
+            bc = port.blobcenter_i32(sat, r)
+            want.append(port.bloblist(flat[i], bc, thr, 0.0, R, mm))
+        ctx = capi.Context(0, n_streams=1)
+        try:
+            ctx.tune("tail_emit_kernel", emit_kernel)
+            if cand_cap:
+                ctx.tune("candidate_capacity", cand_cap)
+            d_flat = dev(torch, flat)
+            d_sat = torch.zeros((B, h, w), dtype=torch.int32, device="cuda")
+            if walker == "table":
+                ctx.graddot_sat(d_flat, w, h, o, B, capi.SAT_TILED, d_sat)
+            for order in (capi.ORDER_RASTER, capi.ORDER_ATOMIC):
+                d_m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda")
+                d_idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+                d_cnt = torch.full((B, 3), -3, dtype=torch.int32, device="cuda")
+                for _ in range(2):  # twice: the self-cleaning queue counters must be back at zero
+                    if walker == "table":
+                        ctx.blobcenter_list(d_flat, d_sat, w, h, B, r, thr, 0.0, R, mm, order, d_m, d_idx, d_cnt)
+                    else:
+                        ctx.flat_bloblist(d_flat, w, h, B, o, r, thr, 0.0, R, mm, order, d_m, d_idx, d_cnt)
+                ctx.sync()
+                for i in range(B):
+                    wm, widx, wcnt = want[i]
+                    cnt = d_cnt[i].cpu().numpy()
+                    assert np.array_equal(cnt, wcnt), (walker, thr, mm, order, i, cnt, wcnt)
+                    gm, gi = capi.sorted_blobs(d_m[i].cpu().numpy(), d_idx[i].cpu().numpy().view(np.uint32), cnt, mm)
+                    if int(cnt[0]) <= mm:
+                        assert np.array_equal(gi, widx) and gm.tobytes() == wm.tobytes(), (walker, thr, mm, order, i)
+                        if order == capi.ORDER_RASTER:
+                            assert np.array_equal(d_idx[i].cpu().numpy().view(np.uint32)[:len(widx)], widx)
+                    else:  # list overflow: which records survive is run-dependent in the reference too (blobList.cl:87-89); every survivor is genuine and unique
+                        assert len(gm) == mm and len(np.unique(gi)) == mm
+            if thr == 0.0:
+                assert int(want[0][2][0]) == h * w  # the constant frame: every pixel was appended
+        finally:
+            ctx.close()

@@ -51,6 +51,7 @@ struct VpTuning {
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
 	int frame_graph = 0;           // vp_frame replays a captured hipGraph of its launches for a repeated (stream, parameters, batch, buffers) tuple (2: no pre-flight, see vp_frame.hip)
+	int tail_emit_kernel = 1;      // walkers: records by a second launch from per-frame survivor queues (1, default) or inside the walker (0)
 	int placement_candidates = 48; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives)
 };
 

@@ -128,6 +128,9 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 	} else if(k == "placement_candidates") {
 		VP_REQUIRE(value >= 0 && value <= 256, "vp_ctx_tune: placement_candidates out of range [0,256]");
 		ctx->tune.placement_candidates = value;
+	} else if(k == "tail_emit_kernel") {
+		VP_REQUIRE(value == 0 || value == 1, "vp_ctx_tune: tail_emit_kernel is 0 or 1");
+		ctx->tune.tail_emit_kernel = value;
 	} else if(k == "tail_segment_rows") {
 		VP_REQUIRE(value >= 0 && value <= 4096, "vp_ctx_tune: tail_segment_rows out of range [0,4096]");
 		ctx->tune.tail_segment_rows = value;

@@ -373,7 +373,27 @@ __device__ __forceinline__ float walk_quot(int m) {
 // test m >= m_thr with m_thr = the smallest integer whose quotient is not below the threshold (found by the host by bisection with the same
 // binary32 division).  Only when some lane of the wavefront passes it (a fraction of a per cent of the rows) are the five blobCenter values
 // formed, the neighbours fetched (left / right by DPP wave shifts; outside the image the pixel's own value: `own > own` is false) and the strict
-// '>' peak test of blobList.cl:47-52 made; survivors become records on the spot (blobList.cl:57-102).  All 64 lanes must be active.
+// '>' peak test of blobList.cl:47-52 made.  All 64 lanes must be active.
+//
+// Survivors do NOT become records inside the walk: they wait in a small per-wavefront queue in LDS (WalkQueue: x, y and the five blobCenter values a
+// record needs) and the wavefront turns them into records (blobList.cl:57-102) AFTER its row loop, when the row windows are dead.  Emitting on the spot
+// kept the disc statistics' ~27 VGPRs and ~26 SGPRs alive beside the windows across the whole loop: k_circle_walk<5> 75 VGPRs / 106 SGPRs = 6 wavefronts
+// per SIMD (both limits; MI355X_MICROARCH.md, Residency) against 8 now -- and the walk is a latency chain whose time is memory round trip / rows in
+// flight.  A queue that is about to run out of room (more than WQ_STOP candidates: clustered robots, or a pathological frame in which every pixel is
+// a plateau peak) ends the walk after the current row; the wavefront drains the queue and walks again from the next row (WalkStop).
+// 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgpr / 16) * 16 + 16)) (MI355X_MICROARCH.md, Residency): 8 needs <= 80 SGPRs.  The
+// walkers' 21 kernel arguments tempt the compiler to 98-106; capped, it re-derives them where they are used (18-23 scalar spills, none in the row loop).
+#define VP_WALK_SGPRS __attribute__((amdgpu_num_sgpr(80)))
+constexpr int WQ_CAP = 96, WQ_STOP = WQ_CAP - 64, WQ_WORDS = 8; // 3 KB per wavefront; a row appends at most 58 candidates (62 - 2r lanes report)
+struct WalkQueue {
+	uint32_t* q; // LDS, this wavefront's [WQ_CAP][WQ_WORDS]: {x, y, v, left | right, up, down, -}
+	int count;   // wave-uniform
+};
+struct WalkStop { // wave-uniform loop state the queue may cut short
+	unsigned det_n; // rows still to be tested (the range test of the row loop)
+	int nsteps;     // row-loop bound
+	int y_resume;   // first row NOT yet tested when the walk ends
+};
 struct WalkEmit {
 	const uint32_t* flat; // this frame
 	int32_t* counter;     // this frame's [3]
@@ -384,7 +404,7 @@ struct WalkEmit {
 };
 template<int R>
 __device__ __forceinline__ void walk_detect(int m_up, int m_mid, int m_dn, bool col_ok, uint64_t col_mask /* ballot of col_ok */, bool x_first, bool x_last, int x, int y, int w, int h, int m_thr,
-		int& rej, const WalkEmit& em, int lane) {
+		int& rej, WalkQueue& wq, WalkStop& ws, int lane) {
 	// blobList.cl:39 for the whole wavefront: one compare, one scalar AND with the (loop-invariant) mask of the reporting lanes, one branch
 	if((__builtin_amdgcn_ballot_w64(m_mid >= m_thr) & col_mask) == 0) return; // wave-uniform
 	const bool above = col_ok && m_mid >= m_thr;
@@ -396,16 +416,44 @@ __device__ __forceinline__ void walk_detect(int m_up, int m_mid, int m_dn, bool 
 	const float uv = y == 0 ? v : walk_quot<R>(m_up), dv = y == h - 1 ? v : walk_quot<R>(m_dn);
 	const bool peak = !(lf > v || rt > v || uv > v || dv > v); // :47-52, strict '>'
 	rej += __popcll(__ballot(above && !peak));                 // :53 counter[2]++
-	unsigned long long cm = __ballot(above && peak);
-	while(cm != 0) { // wave-uniform: one record per survivor
-		const int b = __ffsll((long long)cm) - 1;
-		cm &= cm - 1;
-		const int px = __builtin_amdgcn_readlane(x, b);
-		const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), b));
-		const float cl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), b)), cr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rt), b));
-		const float cu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uv), b)), cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), b));
-		emit_record(em.flat, w, h, px, y, cv, cl, cr, cu, cd, em.min_score, em.list_radius, em.max_matches, em.counter, em.rec, em.idx, lane);
+	const bool hit = above && peak;
+	const unsigned long long cm = __ballot(hit);
+	if(cm == 0) return; // wave-uniform
+	if(hit) { // every survivor queues itself: slot = queue length + survivors in lower lanes
+		const int slot = wq.count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+		uint4* e = reinterpret_cast<uint4*>(wq.q + slot * WQ_WORDS);
+		e[0] = make_uint4((uint32_t)x, (uint32_t)y, __float_as_uint(v), __float_as_uint(lf));
+		e[1] = make_uint4(__float_as_uint(rt), __float_as_uint(uv), __float_as_uint(dv), 0u);
 	}
+	wq.count += __popcll(cm);
+	if(wq.count > WQ_STOP) { // the next row might not fit: this row was the walk's last (its survivors are all queued, its rejects counted)
+		ws.det_n = 0;
+		ws.nsteps = 0;
+		ws.y_resume = y + 1;
+	}
+}
+
+// The queued survivors of a walk, after the row loop.  Two ways out:
+//  * gq != nullptr (large launches): they are handed to the FRAME's queue in global memory (one atomic per wavefront reserves the slots, the entries
+//    are copied 8 words each) and the wavefront is done; k_emit_queue, the next launch, turns every frame's queue into records with one wavefront
+//    per survivor.  Emitting inside the walker costs a record's whole latency chain (disc pixels from HBM -> wave reductions -> returning atomic ->
+//    stores) while the workgroup's other three wavefronts wait at the arrival barrier with their slots occupied: 51 of 337 us at 128 frames.
+//  * otherwise, and for entries the frame's queue has no room for: records on the spot (blobList.cl:57-102), one at a time by the whole wavefront.
+__device__ __forceinline__ void walk_drain(WalkQueue& wq, const WalkEmit& em, int w, int h, int lane, uint32_t* gq /* this frame's queue or nullptr */, int32_t* gq_count, int gq_cap) {
+	int first = 0;
+	if(gq && wq.count) { // wave-uniform
+		int base = 0;
+		if(lane == 0) base = atomicAdd(gq_count, wq.count);
+		base = __builtin_amdgcn_readfirstlane(base);
+		first = max(0, min(wq.count, gq_cap - base)); // entries that fit (the counter may run past the capacity: readers clamp it)
+		for(int i = lane; i < first * WQ_WORDS; i += 64) gq[(size_t)base * WQ_WORDS + i] = wq.q[i]; // read by the NEXT launch: plain stores
+	}
+	for(int i = first; i < wq.count; i++) { // wave-uniform
+		const uint4 a = *reinterpret_cast<const uint4*>(wq.q + i * WQ_WORDS), b = *reinterpret_cast<const uint4*>(wq.q + i * WQ_WORDS + 4); // same address in every lane: broadcast
+		emit_record(em.flat, w, h, (int)a.x, (int)a.y, __uint_as_float(a.z), __uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), em.min_score, em.list_radius,
+				em.max_matches, em.counter, em.rec, em.idx, lane);
+	}
+	wq.count = 0;
 }
 
 // smallest integer m with !(quotient(m) < thr), by bisection (host; the same correctly rounded binary32 division the kernels' quotient equals)
@@ -422,6 +470,203 @@ static int walk_threshold(float thr, int r) {
 		else lo = mid;
 	}
 	return (int)hi;
+}
+
+// The walkers' second launch (large launch groups): every frame's queue of survivors -> records (blobList.cl:57-102) -> the frame's sorted list, by
+// ONE 1024-thread workgroup per frame.  Everything that made record emission slow inside the walkers is a serial chain of memory round trips per
+// record -- disc pixels, the returning atomic_inc, write-through stores, the arrival count, the sorting workgroup reading it all back (16.6 k records
+// of 128 frames: 51 us inside the walkers, 64 us as one wavefront per record in a launch of its own).  Here 8 lanes make one record, 128 records at
+// a time per workgroup: all disc pixels of those records are requested at once (ONE round trip), the sums are reduced over the 8 lanes by DPP, the
+// append slots come from a workgroup prefix sum (blobList.cl:87's atomic_inc once per frame, not per record), the records wait in LDS and are
+// ranked there by pixel index (RASTER) and stored straight into the caller's arrays.  Only a frame whose queue overflowed (the walkers then made
+// the remaining records themselves, walk_drain) goes through the append-order arrays and the generic sort.
+constexpr int EQ_NT = 1024, EQ_GROUP = 8, EQ_PER_PASS = EQ_NT / EQ_GROUP, WALK_GQ_MAX = 1536; // WALK_GQ_MAX: queue entries per frame (LDS staging of the records: 28 B each)
+
+__device__ __forceinline__ uint32_t group8_sum(uint32_t v) { // sum over the 8 lanes of a group (lanes 8g .. 8g+7 of a 16-lane DPP row); every lane gets it
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror: lane i <- lane 7 - i of its half row (the other quad)
+	return v;
+}
+
+// generic RASTER sort of the append-order arrays by NT threads (all of the workgroup): rank = number of records with a smaller pixel index
+template<int NT>
+__device__ __forceinline__ void sort_append_order(int nrec, const uint8_t* rec_work, const uint32_t* idx_work, uint8_t* rec_sorted, uint32_t* idx_sorted, uint32_t* tile /* LDS [NT] */) {
+	const int t = (int)threadIdx.x;
+	for(int t0 = 0; t0 < nrec; t0 += NT) {
+		const int tt = t0 + t;
+		const uint32_t mine = tt < nrec ? ld_wt32(idx_work + tt) : 0;
+		int rank = 0;
+		for(int j0 = 0; j0 < nrec; j0 += NT) {
+			const int j = j0 + t;
+			tile[t] = j < nrec ? ld_wt32(idx_work + j) : 0xFFFFFFFFu;
+			__syncthreads();
+			const int m = min(NT, nrec - j0);
+			for(int j2 = 0; j2 < m; j2++) rank += tile[j2] < mine;
+			__syncthreads();
+		}
+		if(tt < nrec) {
+			const uint16_t* sp = reinterpret_cast<const uint16_t*>(rec_work + (size_t)tt * 22);
+			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_sorted + (size_t)rank * 22);
+#pragma unroll
+			for(int k = 0; k < 11; k++) dp[k] = ld_wt16(sp + k);
+			if(idx_sorted) idx_sorted[rank] = mine;
+		}
+	}
+}
+
+__global__ __launch_bounds__(EQ_NT) void k_emit_queue(const uint32_t* __restrict__ flat, const uint32_t* __restrict__ gq, int32_t* __restrict__ gq_count, int gq_cap,
+		int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work, uint32_t* __restrict__ idx_work, int w, int h, float min_score, int radius, int max_matches, int order,
+		uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+	__shared__ uint32_t s_idx[WALK_GQ_MAX];      // pixel index of the accepted records, append order
+	__shared__ uint16_t s_rec[WALK_GQ_MAX * 12]; // their 22-byte records (24-byte pitch)
+	__shared__ uint32_t tile[EQ_NT];
+	__shared__ int s_acc[EQ_NT / 64], s_rej[EQ_NT / 64], s_base;
+	const int z = blockIdx.x, t = (int)threadIdx.x, lane = t & 63, wv = t >> 6, gl = t & (EQ_GROUP - 1), grp = t / EQ_GROUP;
+	const size_t n = (size_t)w * h;
+	const uint32_t* f = flat + z * n;
+	counter += 3 * z;
+	rec_work += (size_t)z * max_matches * 22;
+	idx_work += (size_t)z * max_matches;
+	rec_sorted += (size_t)z * max_matches * 22;
+	if(idx_sorted) idx_sorted += (size_t)z * max_matches;
+	const int queued = gq_count[z];
+	const int total = min(queued, gq_cap);
+	const bool overflowed = queued > gq_cap; // the walkers made the remaining records themselves: they sit in the append-order arrays already
+	const uint32_t* q = gq + (size_t)z * gq_cap * WQ_WORDS;
+	const int D = 2 * radius + 1, DD = D * D, sq = radius * radius;
+	const float invD = 1.0f / (float)D;
+	int nacc = 0, nrej = 0; // workgroup-uniform running totals
+	__syncthreads();        // every thread has read the queue length ...
+	if(t == 0) gq_count[z] = 0; // ... before it is put back to zero for the next launch (self-cleaning)
+	for(int k0 = 0; k0 < total; k0 += EQ_PER_PASS) { // workgroup-uniform
+		const int k = k0 + grp;
+		const bool active = k < total;
+		uint4 ea = make_uint4(0, 0, 0, 0), eb = ea;
+		if(active) {
+			ea = *reinterpret_cast<const uint4*>(q + (size_t)k * WQ_WORDS);
+			eb = *reinterpret_cast<const uint4*>(q + (size_t)k * WQ_WORDS + 4);
+		}
+		const int px = (int)ea.x, py = (int)ea.y;
+		// disc statistics (blobList.cl:57-73): element e of the (2R+1)^2 square goes to lane e % 8 of the group; four requests in flight per round
+		uint32_t s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0}, cnt = 0;
+		for(int e0 = gl; e0 < DD; e0 += 4 * EQ_GROUP) {
+			uint32_t pv[4];
+			bool in[4];
+#pragma unroll
+			for(int u = 0; u < 4; u++) {
+				const int e = e0 + u * EQ_GROUP;
+				const int row = (int)(((float)e + 0.5f) * invD); // e / D, exact for e < 2^12 (the fraction is at least 0.5 / D away from an integer)
+				const int dy = row - radius, dx = e - row * D - radius;
+				in[u] = active && e < DD && dx * dx + dy * dy <= sq;
+				pv[u] = in[u] ? f[(size_t)vp_clampi(py + dy, 0, h - 1) * w + vp_clampi(px + dx, 0, w - 1)] : 0u;
+			}
+#pragma unroll
+			for(int u = 0; u < 4; u++) {
+				if(in[u]) {
+#pragma unroll
+					for(int c = 0; c < 3; c++) {
+						const uint32_t b = (pv[u] >> (8 * c)) & 0xFF;
+						s1[c] += b;
+						s2[c] += b * b;
+					}
+					cnt++;
+				}
+			}
+		}
+		const uint32_t center = active ? f[(size_t)py * w + px] : 0u;
+		cnt = group8_sum(cnt);
+		const float nf = (float)(int)cnt;
+		float sd[3];
+		uint32_t color[3];
+#pragma unroll
+		for(int c = 0; c < 3; c++) {
+			const uint32_t a1 = group8_sum(s1[c]), a2 = group8_sum(s2[c]);
+			const float a = (float)a1;
+			const float qq = a * a / nf;
+			sd[c] = sqrtf(((float)a2 - qq) / nf); // :76 (native_sqrt -> IEEE sqrt)
+			color[c] = cnt ? a1 / cnt : 0u;        // :96 uint division
+		}
+		const float v = __uint_as_float(ea.z), nx = __uint_as_float(ea.w), qx = __uint_as_float(eb.x), ny = __uint_as_float(eb.y), qy = __uint_as_float(eb.z);
+		const float score = v / (sd[0] + sd[1] + sd[2]); // :78
+		const bool leader = active && gl == 0;
+		const bool rejected = leader && score < min_score; // :79-82 (NaN is kept)
+		const bool accepted = leader && !rejected;
+		// append slots in queue order: survivors of lower groups first (blobList.cl:87, one workgroup-wide prefix sum instead of an atomic per record)
+		const unsigned long long ma = __ballot(accepted), mr = __ballot(rejected);
+		if(lane == 0) {
+			s_acc[wv] = __popcll(ma);
+			s_rej[wv] = __popcll(mr);
+		}
+		__syncthreads();
+		int before = 0, pass_acc = 0, pass_rej = 0;
+#pragma unroll
+		for(int i = 0; i < EQ_NT / 64; i++) {
+			before += i < wv ? s_acc[i] : 0;
+			pass_acc += s_acc[i];
+			pass_rej += s_rej[i];
+		}
+		const int slot = nacc + before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+		if(accepted && slot < WALK_GQ_MAX) {
+			const float mx = (float)px + 0.5f * (nx - qx) / (nx - 2 * v + qx); // :93
+			const float my = (float)py + 0.5f * (ny - qy) / (ny - 2 * v + qy); // :94
+			const uint32_t xb = __float_as_uint(mx), yb = __float_as_uint(my), cb = __float_as_uint(v), sb = __float_as_uint(score);
+			uint16_t* d = s_rec + slot * 12;
+			d[0] = (uint16_t)xb; d[1] = (uint16_t)(xb >> 16);
+			d[2] = (uint16_t)yb; d[3] = (uint16_t)(yb >> 16);
+			d[4] = (uint16_t)(color[0] | (color[1] << 8));
+			d[5] = (uint16_t)(color[2] | ((center & 0xFF) << 8));
+			d[6] = (uint16_t)(((center >> 8) & 0xFF) | (((center >> 16) & 0xFF) << 8));
+			d[7] = (uint16_t)cb; d[8] = (uint16_t)(cb >> 16);
+			d[9] = (uint16_t)sb; d[10] = (uint16_t)(sb >> 16);
+			s_idx[slot] = (uint32_t)(py * w + px);
+		}
+		nacc += pass_acc;
+		nrej += pass_rej;
+		__syncthreads(); // s_acc / s_rej are rewritten by the next pass
+	}
+	// counters (blobList.cl:80,87): once per frame
+	if(t == 0) {
+		if(nrej) atomicAdd(&counter[1], nrej);
+		s_base = nacc ? atomicAdd(&counter[0], nacc) : (overflowed ? __hip_atomic_load(&counter[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
+	}
+	__syncthreads();
+	const int base = s_base;
+	const bool raster = order == VP_ORDER_RASTER;
+	if(!overflowed) { // (base == 0: nobody else appended to this frame) the records are all here: rank in LDS, store once
+		const int nrec = min(nacc, max_matches); // :88-89: entries past the capacity are never written
+		for(int i = t; i < nrec; i += EQ_NT) {
+			const uint32_t mine = s_idx[i];
+			int rank = i;
+			if(raster) {
+				rank = 0;
+				for(int j = 0; j < nrec; j++) rank += s_idx[j] < mine;
+			}
+			const uint16_t* sp = s_rec + i * 12;
+			uint16_t* dp = reinterpret_cast<uint16_t*>((raster ? rec_sorted : rec_work) + (size_t)rank * 22);
+#pragma unroll
+			for(int k2 = 0; k2 < 11; k2++) dp[k2] = sp[k2];
+			uint32_t* ip = raster ? idx_sorted : idx_work;
+			if(ip) ip[rank] = mine;
+		}
+		return;
+	}
+	// overflowed queue: our records join the walkers' in the append-order arrays (write-through: the sort below reads them back with sc1 loads)
+	for(int i = t; i < nacc; i += EQ_NT) {
+		const int dst = base + i;
+		if(dst < max_matches) {
+			const uint16_t* sp = s_rec + i * 12;
+			uint16_t* dp = reinterpret_cast<uint16_t*>(rec_work + (size_t)dst * 22);
+#pragma unroll
+			for(int k2 = 0; k2 < 11; k2++) st_wt16(dp + k2, sp[k2]);
+			__hip_atomic_store((gu32_t*)(idx_work + dst), s_idx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	if(!raster) return;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	const int nrec = min(__hip_atomic_load(&counter[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), max_matches);
+	sort_append_order<EQ_NT>(nrec, rec_work, idx_work, rec_sorted, idx_sorted, tile);
 }
 
 // ---------------------------------------------------------------- circle + detect, fused --------------------------------------
@@ -445,11 +690,13 @@ static int walk_threshold(float thr, int r) {
 // outside the image take the pixel's own value: that is what the reference's clamped reads return, and `own > own` is false.
 
 template<int RT, bool BCOUT>
-__global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, const uint32_t* __restrict__ flat, int32_t* __restrict__ done,
+__global__ __launch_bounds__(256) VP_WALK_SGPRS void k_circle_walk(const int32_t* __restrict__ sat_all, float* __restrict__ bc_out, const uint32_t* __restrict__ flat, int32_t* __restrict__ done,
 		int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work, uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame,
-		float thr, int m_thr, float min_score, int list_radius, int max_matches, int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+		float thr, int m_thr, float min_score, int list_radius, int max_matches, int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted,
+		uint32_t* __restrict__ gq /* frames' survivor queues, or nullptr: records are made here */, int32_t* __restrict__ gq_count, int gq_cap) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
+	__shared__ __attribute__((aligned(16))) uint32_t wqueue[4 * WQ_CAP * WQ_WORDS];
 	// PF rows of loads in flight per lane (a walk is one dependent chain per lane).  With 4 the kernel held 7 MB in flight on the whole chip, half of
 	// what HBM latency x bandwidth asks for: 128 frames 0.379 ms; 8 and more: 0.354 (12 and 16 no better).  WL (window length, >= 2r+1) must be a
 	// multiple of PF, so PF is chosen per radius to keep the windows tight: 2r+1 itself up to 13, about half of it above.
@@ -474,6 +721,9 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	const bool col_ok = lane >= R + 1 && lane <= 62 - R && x < w; // (x >= 0 for these lanes)
 	const uint64_t col_mask = __builtin_amdgcn_ballot_w64(col_ok);
 	const bool x_first = x == 0, x_last = x == w - 1;
+	int rej = 0;
+	WalkQueue wq = {wqueue + (threadIdx.x >> 6) * (WQ_CAP * WQ_WORDS), 0};
+	for(int ys = ya; ys < yb;) { // one walk from row ys to the segment's end, or to the row after which the survivor queue had to be drained
 	// Windows of the last WL >= 2r+1 rows of -D1 / D2, and the raw SAT values of the next PF rows in flight: a row's load is
 	// issued PF steps before it is used (a walk is one dependent chain per lane; without the run-ahead every step would wait a full
 	// memory round trip).  WL is a multiple of PF and the loop is unrolled WL-fold, so every array index below is a constant.
@@ -481,17 +731,17 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 #pragma unroll
 	for(int j = 0; j < WL; j++) D1[j] = D2[j] = 0;
 	int m_up = 0, m_mid = 0; // integer quadrant minimum (blobCenter * r^2) of rows t-2, t-1 while row t is being formed
-	int rej = 0;
-	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
-	const int s0 = ya - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ya - 1 at k = 2r, when the windows are full
-	const int nsteps = 2 * R + (yb - ya) + 2;
-	const int row_hi = min(h - 1, s0 + nsteps - 1 + R); // the run-ahead past the last step re-reads the segment's last row (a cache hit) instead of rows nobody needs
+	const int s0 = ys - 1 - 2 * R;                 // step k feeds SAT row t + r and completes blobCenter row t = s0 + k: row ys - 1 at k = 2r, when the windows are full
+	WalkStop ws;
+	ws.nsteps = 2 * R + (yb - ys) + 2;
+	ws.y_resume = yb;
+	const int row_hi = min(h - 1, s0 + ws.nsteps - 1 + R); // the run-ahead past the last step re-reads the segment's last row (a cache hit) instead of rows nobody needs
 	// The scalar side of a row step is kept short on purpose (it was 19 scalar instructions against 12 vector ones and filled 61 % of the scalar
 	// issue slots): the byte offset of the next row to request runs along as ONE scalar (add, max, min: clamp-to-edge of satBlobCenter.cl:20 and
 	// the segment's last row), and "windows full and row inside the segment" is ONE unsigned range test.
 	int so_next = (s0 + R) * (int)row_bytes;            // row s0 + K + R of the K-th request (negative above the image: clamped when used)
 	const int so_hi = row_hi * (int)row_bytes;
-	const unsigned det_n = (unsigned)max(0, yb - s0 + 1 - (2 * R + 2)); // steps 2r+2 .. 2r+2+det_n-1 complete a row y = s0 + k - 1 < yb with full windows
+	ws.det_n = (unsigned)max(0, yb - s0 + 1 - (2 * R + 2)); // steps 2r+2 .. 2r+2+det_n-1 complete a row y = s0 + k - 1 < yb with full windows
 #define VP_WK_ISSUE(SLOT, K)                                                                                                           \
 	do {                                                                                                                               \
 		Pe[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)min(max(so_next, 0), so_hi), 0); /* request number K, in order */ \
@@ -499,7 +749,7 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 	} while(0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_WK_ISSUE(p, p);
-	for(int kb = 0; kb < nsteps; kb += WL) {
+	for(int kb = 0; kb < ws.nsteps; kb += WL) {
 #pragma unroll
 		for(int j = 0; j < WL; j++) {
 			const int k = kb + j;
@@ -520,16 +770,22 @@ __global__ __launch_bounds__(256) void k_circle_walk(const int32_t* __restrict__
 			const int np = (int)((uint32_t)D2[jp1] - (uint32_t)D2[j]), nn = (int)((uint32_t)D2[jm1] - (uint32_t)D2[jmr]);
 			const int m_dn = min(min(pp, nn), min(pn, np)); // blobCenter(x, t) * r^2, t = s0 + k (satBlobCenter.cl:41)
 			const int t = s0 + k;
-			if(BCOUT && k >= 2 * R && t >= ya && t < yb && col_ok) bc_out[z * n + (size_t)t * w + x] = walk_quot<R>(m_dn);
+			if(BCOUT && k >= 2 * R && t >= ys && t < yb && col_ok) bc_out[z * n + (size_t)t * w + x] = walk_quot<R>(m_dn);
 			const int y = t - 1; // the row whose four neighbours are now known
-			if((unsigned)(k - (2 * R + 2)) < det_n) walk_detect<R>(m_up, m_mid, m_dn, col_ok, col_mask, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			if((unsigned)(k - (2 * R + 2)) < ws.det_n) walk_detect<R>(m_up, m_mid, m_dn, col_ok, col_mask, x_first, x_last, x, y, w, h, m_thr, rej, wq, ws, lane); // scalar condition
 			m_up = m_mid;
 			m_mid = m_dn;
 		}
 	}
 #undef VP_WK_ISSUE
+	// the walk's survivors -> records, now that the windows are dead (see WalkQueue)
+	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
+	walk_drain(wq, em, w, h, lane, gq ? gq + (size_t)z * gq_cap * WQ_WORDS : nullptr, gq_count + z, gq_cap);
+	ys = ws.y_resume;
+	}
 	if(rej != 0 && lane == 0) atomicAdd(&counter[3 * z + 2], rej);
 	} // item < items_per_frame
+	if(gq) return; // k_emit_queue makes the records and sorts them
 	frame_arrive_and_sort(done + (size_t)z * ARRIVE_WORDS, (int)(lb - (unsigned)z * (unsigned)wgs_per_frame), wgs_per_frame, nullptr, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, max_matches, order,
 			rec_sorted + (size_t)z * max_matches * 22, idx_sorted ? idx_sorted + (size_t)z * max_matches : nullptr, tile, &s_last);
 }
@@ -568,11 +824,12 @@ __device__ __forceinline__ int lane_window_sum(int v, int lane) { // sum of v ov
 }
 
 template<int RT, int OT>
-__global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ flat, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work,
+__global__ __launch_bounds__(256) VP_WALK_SGPRS void k_flat_walk(const uint32_t* __restrict__ flat, int32_t* __restrict__ done, int32_t* __restrict__ counter, uint8_t* __restrict__ rec_work,
 		uint32_t* __restrict__ idx_work, int w, int h, int seg_h, int strips_x, int items_per_frame, int wgs_per_frame, float thr, int m_thr, float min_score, int list_radius, int max_matches,
-		int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted) {
+		int order, uint8_t* __restrict__ rec_sorted, uint32_t* __restrict__ idx_sorted, uint32_t* __restrict__ gq, int32_t* __restrict__ gq_count, int gq_cap) {
 	__shared__ uint32_t tile[256];
 	__shared__ int s_last;
+	__shared__ __attribute__((aligned(16))) uint32_t wqueue[4 * WQ_CAP * WQ_WORDS]; // survivors wait here until the row loop is over (WalkQueue)
 	constexpr int R = RT, O = OT, PF = 8, NB = R - 1;                        // NB: box side; PF rows of loads in flight per lane (see k_circle_walk: 4 were too few)
 	constexpr int WFL = ((2 * O + 1 + PF - 1) / PF) * PF;                     // own-column flat window (rows t'-o .. t'+o), a multiple of PF
 	constexpr int RING = ((R + 2 + WFL - 1) / WFL) * WFL;                     // ring length of the row windows: >= r+2, a multiple of WFL; the loop is unrolled RING-fold
@@ -596,22 +853,26 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	const bool col_ok = lane >= LO && lane <= HI && x < w;                 // this lane reports blobs (x >= 0 for these lanes)
 	const uint64_t col_mask = __builtin_amdgcn_ballot_w64(col_ok);
 	const bool x_first = x == 0, x_last = x == w - 1;
+	int rej = 0;
+	WalkQueue wq = {wqueue + (threadIdx.x >> 6) * (WQ_CAP * WQ_WORDS), 0};
+	for(int ys = ya; ys < yb;) { // one walk from row ys to the segment's end, or to the row after which the survivor queue had to be drained
 	uint32_t FW[WFL], Pe[PF]; // own-column flat values of the last WFL rows; flat values of the next PF rows in flight
 	int GW[RING], BP[RING], BN[RING]; // gradientDot of the data column, B(x+2, .), B(x-r+1, .) of the last RING rows
 #pragma unroll
 	for(int j = 0; j < WFL; j++) FW[j] = 0;
 #pragma unroll
 	for(int j = 0; j < RING; j++) GW[j] = BP[j] = BN[j] = 0;
-	int V = 0, rej = 0, m_up = 0, m_mid = 0; // V: sum of the last r-1 gradientDot rows of the data column; m_*: integer quadrant minimum of rows y-2, y-1
-	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
-	// step k loads flat row f = f0 + k, forms gradientDot row t' = f - o (from k = 2o on: row ya - r, the first row of the first box needed) and
+	int V = 0, m_up = 0, m_mid = 0; // V: sum of the last r-1 gradientDot rows of the data column; m_*: integer quadrant minimum of rows y-2, y-1
+	// step k loads flat row f = f0 + k, forms gradientDot row t' = f - o (from k = 2o on: row ys - r, the first row of the first box needed) and
 	// the box row B(., t'), the quadrant minimum of row y = t' - r (boxes ending at rows y + r and y - 1) and tests row y - 1
-	const int f0 = ya - R - O;
-	const int nsteps = 2 * R + 2 * O + 1 + (yb - ya);
-	const int row_hi = min(h - 1, f0 + nsteps - 1); // the run-ahead past the last step re-reads the segment's last row (a cache hit)
+	const int f0 = ys - R - O;
+	WalkStop ws;
+	ws.nsteps = 2 * R + 2 * O + 1 + (yb - ys);
+	ws.y_resume = yb;
+	const int row_hi = min(h - 1, f0 + ws.nsteps - 1); // the run-ahead past the last step re-reads the segment's last row (a cache hit)
 	int so_next = f0 * (int)row_bytes;                  // scalar side kept short, see k_circle_walk: running byte offset of the next request ...
 	const int so_hi = row_hi * (int)row_bytes;
-	const unsigned det_n = (unsigned)max(0, yb + R + O + 1 - f0 - (2 * R + 2 * O + 1)); // ... and one range test: y = f0 + k - O - R - 1 < yb
+	ws.det_n = (unsigned)max(0, yb + R + O + 1 - f0 - (2 * R + 2 * O + 1)); // ... and one range test: y = f0 + k - O - R - 1 < yb
 #define VP_FW_ISSUE(SLOT, K)                                                                                                           \
 	do {                                                                                                                               \
 		Pe[SLOT] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, oe, (uint32_t)min(max(so_next, 0), so_hi), 0);                   \
@@ -619,7 +880,7 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 	} while(0)
 #pragma unroll
 	for(int p = 0; p < PF; p++) VP_FW_ISSUE(p, p);
-	for(int kb = 0; kb < nsteps; kb += RING) {
+	for(int kb = 0; kb < ws.nsteps; kb += RING) {
 #pragma unroll
 		for(int j = 0; j < RING; j++) {
 			const int k = kb + j;
@@ -641,14 +902,19 @@ __global__ __launch_bounds__(256) void k_flat_walk(const uint32_t* __restrict__ 
 			const int jo = (j - (R + 1) + 2 * RING) % RING;   // row t' - r - 1 = y - 1
 			const int m_dn = min(min(BP[j], BN[jo]), -max(BP[jo], BN[j])); // min(pp, nn, pn, np) of row y = t' - r (satBlobCenter.cl:37-41, times r^2)
 			const int y = tq - R - 1; // the row whose four neighbours are now known
-			if((unsigned)(k - (2 * R + 2 * O + 1)) < det_n) walk_detect<R>(m_up, m_mid, m_dn, col_ok, col_mask, x_first, x_last, x, y, w, h, m_thr, rej, em, lane); // scalar condition
+			if((unsigned)(k - (2 * R + 2 * O + 1)) < ws.det_n) walk_detect<R>(m_up, m_mid, m_dn, col_ok, col_mask, x_first, x_last, x, y, w, h, m_thr, rej, wq, ws, lane); // scalar condition
 			m_up = m_mid;
 			m_mid = m_dn;
 		}
 	}
 #undef VP_FW_ISSUE
+	const WalkEmit em = {flat + z * n, counter + 3 * z, rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, min_score, list_radius, max_matches};
+	walk_drain(wq, em, w, h, lane, gq ? gq + (size_t)z * gq_cap * WQ_WORDS : nullptr, gq_count + z, gq_cap);
+	ys = ws.y_resume;
+	}
 	if(rej != 0 && lane == 0) atomicAdd(&counter[3 * z + 2], rej);
 	} // item < items_per_frame
+	if(gq) return; // k_emit_queue makes the records and sorts them
 	frame_arrive_and_sort(done + (size_t)z * ARRIVE_WORDS, (int)(lb - (unsigned)z * (unsigned)wgs_per_frame), wgs_per_frame, nullptr, counter + 3 * z,
 			rec_work + (size_t)z * max_matches * 22, idx_work + (size_t)z * max_matches, max_matches, order,
 			rec_sorted + (size_t)z * max_matches * 22, idx_sorted ? idx_sorted + (size_t)z * max_matches : nullptr, tile, &s_last);
@@ -659,6 +925,22 @@ int vp_sat_common(VpContext* ctx, int stream, const void* in, bool fused, int w,
 		int32_t* zero3, bool* zeroed); // vp_sat.hip
 int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, const float* blobcenter, const int32_t* sat, int circle_radius, float* bc_out,
 		int w, int h, int batch, float thr, float min_score, int radius, int max_matches, int order, VpMatch* matches, uint32_t* idx, int32_t* counter, bool counters_zeroed);
+
+// Walkers, two launches (WalkQueue, walk_drain): the survivors go through the frames' queues in global memory -- the candidate list's memory, 8 words
+// per entry -- to k_emit_queue.  Measured against records made inside the walker (cfg2, circle + blobList alone): 128 frames 344 -> 295 us, 32: 108 -> 90,
+// 8: 44.3 -> 38.8, 4: 34.8 -> 34.3, 1: 24.4 -> 24.0 (profiles/r04_tail_emit_queue.json): never slower, so it is the default at every launch size.
+// vp_ctx_tune "tail_emit_kernel" 0 keeps the records inside the walker (also what happens to survivors a full queue has no room for).
+static int walk_queue_cap(const VpContext* ctx, int batch, const ListScratch& ws) {
+	(void)batch;
+	const bool on = ctx->tune.tail_emit_kernel != 0;
+	return on && (ws.cap % WQ_WORDS) == 0 ? min(ws.cap / WQ_WORDS, WALK_GQ_MAX) : 0; // 0: records are made inside the walker
+}
+static int walk_emit_launch(VpContext* ctx, hipStream_t s, const ListScratch& ws, int gq_cap, const uint32_t* flat, int32_t* counter, uint8_t* rec_work, uint32_t* idx_work, int w, int h, int batch,
+		float min_score, int radius, int max_matches, int order, uint8_t* rec_sorted, uint32_t* idx_sorted) {
+	if(gq_cap <= 0) return VP_OK;
+	k_emit_queue<<<batch, EQ_NT, 0, s>>>(flat, ws.cand, ws.cand_count, gq_cap, counter, rec_work, idx_work, w, h, min_score, radius, max_matches, order, rec_sorted, idx_sorted);
+	return vp_launch_ok("blobList records");
+}
 
 // the (circle radius, gradient offset) pairs k_flat_walk is instantiated for (the VP_FW list below)
 bool vp_flat_walk_supported(int r, int o) {
@@ -710,16 +992,20 @@ int vp_flat_bloblist_impl(VpContext* ctx, int stream, const uint8_t* flat, int w
 	const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flat);
 	uint8_t* msorted = reinterpret_cast<uint8_t*>(matches);
 	const int m_thr = walk_threshold(thr, circle_radius);
+	const int gq_cap = walk_queue_cap(ctx, batch, ws);
+	uint32_t* gq = gq_cap ? ws.cand : nullptr;
 	bool launched = false;
 #define VP_FW(R, OO) \
 	if(!launched && circle_radius == R && grad_offset == OO) { \
-		k_flat_walk<R, OO><<<grid, 256, 0, s>>>(f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx); \
+		k_flat_walk<R, OO><<<grid, 256, 0, s>>>(f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx, gq, \
+				ws.cand_count, gq_cap); \
 		launched = true; \
 	}
 	VP_FW(2, 1) VP_FW(3, 1) VP_FW(4, 1) VP_FW(5, 2) VP_FW(6, 2) VP_FW(7, 2) VP_FW(7, 3) VP_FW(8, 3) VP_FW(9, 3) VP_FW(9, 4) VP_FW(10, 4) VP_FW(11, 4) VP_FW(12, 4)
 #undef VP_FW
 	VP_REQUIRE(launched, "VP_SAT_LOCAL: vp_flat_walk_supported() and the kernel list disagree on (%d, %d)", circle_radius, grad_offset);
-	return vp_launch_ok("gradientDot+circle+blobList (local table)");
+	VP_TRY(vp_launch_ok("gradientDot+circle+blobList (local table)"));
+	return walk_emit_launch(ctx, s, ws, gq_cap, f32, counter, rec_work, idx_work, w, h, batch, min_score, radius, max_matches, order, msorted, idx);
 }
 
 // Run-time radius fallback (radii outside the specialised range): the SAT tile (+ r+1 halo) is staged in LDS with clamp-to-edge
@@ -826,16 +1112,19 @@ int vp_list_from_blobcenter(VpContext* ctx, int stream, const uint8_t* flat, con
 		const uint32_t* f32 = reinterpret_cast<const uint32_t*>(flat);
 		uint8_t* msorted = reinterpret_cast<uint8_t*>(matches);
 		const int m_thr = walk_threshold(thr, circle_radius);
+		const int gq_cap = walk_queue_cap(ctx, batch, ws);
+		uint32_t* gq = gq_cap ? ws.cand : nullptr;
 #define VP_WK(R) \
 		case R: \
-			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx); \
-			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx); \
+			if(bc_out) k_circle_walk<R, true><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx, gq, ws.cand_count, gq_cap); \
+			else k_circle_walk<R, false><<<grid, 256, 0, s>>>(sat, bc_out, f32, ws.done, counter, rec_work, idx_work, w, h, seg_h, strips_x, (int)ipf, (int)wpf, thr, m_thr, min_score, radius, max_matches, order, msorted, idx, gq, ws.cand_count, gq_cap); \
 			break
 		switch(circle_radius) { // the radii real geometries produce (ceil(20 mm / fieldScale))
 			VP_WK(2); VP_WK(3); VP_WK(4); VP_WK(5); VP_WK(6); VP_WK(7); VP_WK(8); VP_WK(9); VP_WK(10); VP_WK(11); VP_WK(12);
 		}
 #undef VP_WK
-		return vp_launch_ok("circle+blobList");
+		VP_TRY(vp_launch_ok("circle+blobList"));
+		return walk_emit_launch(ctx, s, ws, gq_cap, f32, counter, rec_work, idx_work, w, h, batch, min_score, radius, max_matches, order, msorted, idx);
 	} else {
 		const int halo = circle_radius + 1;
 		const size_t lds = sizeof(uint32_t) * ((size_t)(FT_W + 2 * halo) * (FT_H + 2 * halo) + (size_t)(FT_W + circle_radius + 3) * (FT_H + circle_radius + 3));
