@@ -97,7 +97,7 @@ const char* vp_device_name(VpContext* ctx);
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "tail_emit_kernel" 0 / 1 (default 1: the walkers' survivors become records in a second
  *   launch, one workgroup per frame; 0: inside the walker), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
- *   write the dense halo strips the tiled SAT pass reads), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
+ *   write the dense halo strips the tiled SAT pass reads), "placement_max_mib" n (default 0: MiB a placement search may hold at once, 0 = half of the free memory), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
  *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 / 2 (default 0; 1: vp_frame captures the launches of a (stream, parameters, batch,
  *   buffers) call into a hipGraph when the call follows itself on the stream and replays the graph from then on; a stream whose state belongs to another
  *   tuple -- another launch shape, another geometry -- takes the ordinary path, which repairs it; calls with stage events enabled or debug views always
@@ -129,13 +129,15 @@ int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int wri
  * 3.8-4.4 TB/s zero-fill; reads are not affected), decided by where the allocation landed.  The reference allocates its images once and keeps them
  * (OpenCL::acquire pool, opencl.cpp:108-122; CLArray, opencl.cpp:137-159), so the draw is made once: vp_malloc_device_placed allocates up to
  * "placement_candidates" (vp_ctx_tune, default 48) blocks without freeing, times a zero-fill of each (vp_probe_stream), hands out the `count`
- * fastest (dptrs[0] the fastest) and frees the rest; it stops early once `count` blocks reach the fast rate and never holds more than half of the
- * free device memory.  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
+ * fastest (dptrs[0] the fastest) and frees the rest.  It stops early -- judged relative to what it has seen, no device-specific rate -- once `count`
+ * blocks lie within 4 % of the best seen and either a block >= 10 % slower has shown two populations or sixteen candidates all look alike; it never holds
+ * more than half of the free device memory, or "placement_max_mib" MiB (vp_ctx_tune, default 0 = that half), so that a second context or process on the
+ * GPU keeps room.  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
 typedef struct {
 	float write_gbs;            /* zero-fill rate of this block, GB/s (0 when nothing was probed) */
 	float best_gbs, worst_gbs;  /* over the candidates probed for the request */
 	int32_t candidates;         /* blocks allocated and probed */
-	int32_t selected;           /* 1 = chosen among candidates, 0 = plain hipMalloc */
+	int32_t selected;           /* 0 = plain hipMalloc; chosen among candidates: 1 = the search met its stop criterion, 2 = it ran out of candidates, bytes or memory first */
 } VpPlacement;
 int vp_malloc_device_placed(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info /* count entries, or NULL */);
 int vp_copy_h2d(VpContext* ctx, int stream, void* dst_d, const void* src_h, size_t bytes);

@@ -30,6 +30,7 @@ while time.time() - t0 < budget:
     variant = [capi.SAT_TILED, capi.SAT_TILED, capi.SAT_LOCAL, capi.SAT_LOCAL, capi.SAT_TWOPASS][int(rng.integers(5))]
     ctx.tune("tail_segment_rows", int(rng.choice([0, 0, 16, 32, 128])))
     ctx.tune("sat_workgroups_per_cu", int(rng.choice([0, 0, 2, 3, 6])))
+    ctx.tune("tail_emit_kernel", int(rng.choice([1, 1, 1, 0])))
     mm = cfg.max_matches
     raws = [cfg.synth(seed + i) for i in range(B)]
     seed += B

@@ -43,7 +43,7 @@ class VpPlacement(C.Structure):
 
     def as_dict(self):
         return {"write_gbs": round(self.write_gbs, 1), "best_gbs": round(self.best_gbs, 1), "worst_gbs": round(self.worst_gbs, 1), "candidates": int(self.candidates),
-                "selected": bool(self.selected)}
+                "selected": bool(self.selected), "search": {0: "none", 1: "criterion met", 2: "budget exhausted"}.get(int(self.selected), "?")}
 
 
 VIEW_PLANES, VIEW_GRADDOT, VIEW_BLOBCENTER = 1, 2, 4

@@ -33,7 +33,11 @@ int vp_probe_stream_impl(VpContext* ctx, int stream, void* ptr, size_t bytes, in
 	VP_TRY(vp_workspace(ctx, stream, 0, 256, &sink));
 	hipEvent_t e0, e1;
 	VP_CHECK_HIP(hipEventCreate(&e0));
-	VP_CHECK_HIP(hipEventCreate(&e1));
+	if(hipEventCreate(&e1) != hipSuccess) {
+		(void)hipEventDestroy(e0);
+		vp_set_error("vp_probe_stream: hipEventCreate failed");
+		return VP_ERR_HIP;
+	}
 	const unsigned grid = (unsigned)ctx->cu_count * 16;
 	const size_t n16 = bytes / 16;
 	for(int i = -1; i < reps; i++) {
@@ -64,6 +68,11 @@ extern "C" int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t byt
 // consecutive allocations = 33 GB all fast, ~30 % of 100 overall) and leaves read streams untouched (6.7-6.9 TB/s everywhere).  The SAT pass writes
 // its table once per launch: 608 us into a fast allocation, 650-705 us into a slow one.  So: allocate candidates WITHOUT freeing (a freed block is
 // handed out again by the next hipMalloc), probe each, keep the fastest, free the rest.
+// When to stop is decided RELATIVE to what the search has seen (no device-specific rate): once `count` blocks lie within 4 % of the best seen AND
+// either a block at least 10 % slower than the best has shown that there are two populations on this device, or sixteen candidates all look alike (one
+// population, or 0.7^16 = 0.3 % of bad luck on a device where 30 % of the blocks are fast: nothing to choose).  The search never holds more than "placement_max_mib" (vp_ctx_tune; 0 = half of the free memory) at once: a second
+// context or process on the same GPU keeps room.  VpPlacement.selected says how it ended: 1 = criterion met, 2 = budget (candidates or bytes) or memory
+// ran out first and the best blocks seen were kept.
 int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info) {
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	for(int i = 0; i < count; i++) dptrs[i] = nullptr;
@@ -81,8 +90,9 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 	};
 	size_t free_b = 0, total_b = 0;
 	VP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
-	const size_t spend = free_b / 2; // never hold more than half of what is free while searching
-	int good = 0;
+	size_t spend = free_b / 2; // never hold more than half of what is free while searching
+	if(ctx->tune.placement_max_mib > 0) spend = std::min(spend, (size_t)ctx->tune.placement_max_mib << 20);
+	bool met = false;
 	while((int)cands.size() < (select ? budget : count)) {
 		if(select && (int)cands.size() >= count && (cands.size() + 1) * bytes > spend) break;
 		void* p = nullptr;
@@ -104,12 +114,24 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 		}
 		const float gbs = us > 0.f ? (float)((double)bytes / us * 1e-3) : 0.f;
 		cands.push_back({p, gbs});
-		if(select && gbs >= VP_PLACEMENT_FAST_GBS && ++good >= count) break;
+		if(select && (int)cands.size() >= count) {
+			float best = 0.f, worst = gbs;
+			for(const Cand& c : cands) {
+				best = std::max(best, c.gbs);
+				worst = std::min(worst, c.gbs);
+			}
+			int near_best = 0;
+			for(const Cand& c : cands) near_best += c.gbs >= 0.96f * best;
+			if(near_best >= count && (worst <= 0.90f * best || cands.size() >= 16)) {
+				met = true;
+				break;
+			}
+		}
 	}
 	std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.gbs > b.gbs; });
 	for(int i = 0; i < count; i++) {
 		dptrs[i] = cands[i].p;
-		if(info) info[i] = VpPlacement{cands[i].gbs, cands.front().gbs, cands.back().gbs, (int32_t)cands.size(), select ? 1 : 0};
+		if(info) info[i] = VpPlacement{cands[i].gbs, cands.front().gbs, cands.back().gbs, (int32_t)cands.size(), select ? (met ? 1 : 2) : 0};
 	}
 	for(size_t i = count; i < cands.size(); i++) (void)hipFree(cands[i].p);
 	return VP_OK;

@@ -52,6 +52,7 @@ struct VpTuning {
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
 	int frame_graph = 0;           // vp_frame replays a captured hipGraph of its launches for a repeated (stream, parameters, batch, buffers) tuple (2: no pre-flight, see vp_frame.hip)
 	int tail_emit_kernel = 1;      // walkers: records by a second launch from per-frame survivor queues (1, default) or inside the walker (0)
+	int placement_max_mib = 0;     // vp_malloc_device_placed: MiB the search may hold at once (0 = half of the free device memory)
 	int placement_candidates = 48; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives)
 };
 
@@ -136,7 +137,6 @@ int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out,
 void vp_frame_graphs_clear(VpContext* ctx); // vp_frame.hip
 // vp_alloc.hip
 int vp_probe_stream_impl(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us);
-#define VP_PLACEMENT_FAST_GBS 4700.f // zero-fill rate that separates the two populations of 1.6 GB allocations on MI355X (4.95-5.4 vs 3.8-4.4 TB/s)
 
 // RAII bracket for per-stage hipEvent timing (the cl::Event list of opencl.h:84)
 struct VpStageTimer {

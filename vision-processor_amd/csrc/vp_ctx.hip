@@ -125,6 +125,9 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 		VP_REQUIRE(value >= 0 && value <= 2, "vp_ctx_tune: frame_graph is 0, 1 or 2");
 		ctx->tune.frame_graph = value;
 		if(!value) vp_frame_graphs_clear(ctx);
+	} else if(k == "placement_max_mib") {
+		VP_REQUIRE(value >= 0, "vp_ctx_tune: placement_max_mib must not be negative");
+		ctx->tune.placement_max_mib = value;
 	} else if(k == "placement_candidates") {
 		VP_REQUIRE(value >= 0 && value <= 256, "vp_ctx_tune: placement_candidates out of range [0,256]");
 		ctx->tune.placement_candidates = value;
