@@ -129,10 +129,10 @@ int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int wri
  * 3.8-4.4 TB/s zero-fill; reads are not affected), decided by where the allocation landed.  The reference allocates its images once and keeps them
  * (OpenCL::acquire pool, opencl.cpp:108-122; CLArray, opencl.cpp:137-159), so the draw is made once: vp_malloc_device_placed allocates up to
  * "placement_candidates" (vp_ctx_tune, default 48) blocks without freeing, times a zero-fill of each (vp_probe_stream), hands out the `count`
- * fastest (dptrs[0] the fastest) and frees the rest.  It stops early -- judged relative to what it has seen, no device-specific rate -- once `count`
- * blocks lie within 4 % of the best seen and either a block >= 10 % slower has shown two populations or sixteen candidates all look alike; it never holds
- * more than half of the free device memory, or "placement_max_mib" MiB (vp_ctx_tune, default 0 = that half), so that a second context or process on the
- * GPU keeps room.  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
+ * fastest (dptrs[0] the fastest) and frees the rest.  It stops early once `count` blocks write at 0.70 or more of the read-stream rate it measured on
+ * the first candidate (a ratio of two measurements of this device, not an MI355X constant: fast blocks reach 0.74-0.81, slow ones 0.57-0.66), or once
+ * sixteen candidates lie within 6 % of each other; it never holds more than half of the free device memory, or "placement_max_mib" MiB (vp_ctx_tune,
+ * default 0 = that half), so that a second context or process on the GPU keeps room.  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
 typedef struct {
 	float write_gbs;            /* zero-fill rate of this block, GB/s (0 when nothing was probed) */
 	float best_gbs, worst_gbs;  /* over the candidates probed for the request */

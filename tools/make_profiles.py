@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def _csv_under(name, suffix):
@@ -63,8 +63,11 @@ for variant, names in (("local", ("k_flat_walk",)), ("nearest", ("k_resample_sta
     st = os.path.join(P, f"stats_{variant}")
     if os.path.isdir(st):
         shutil.copy(_csv_under(f"stats_{variant}", "kernel_stats.csv"), os.path.join(OUT, f"{tag}_kernel_stats_{variant}.csv"))
-old_path = os.path.join(OUT, "r02_pmc_hbm.json")
-old = json.load(open(old_path)) if os.path.exists(old_path) else {}
+old = {}
+for prev in ("r03_pmc_hbm.json", "r02_pmc_hbm.json"):  # the correction note and the membench calibration are carried along
+    if os.path.exists(os.path.join(OUT, prev)):
+        old = json.load(open(os.path.join(OUT, prev)))
+        break
 frames = bench["config"]["frames_per_step_per_gpu"]
 doc = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2  (tools/profile_round.sh)",
@@ -110,7 +113,7 @@ for run in ("sq_default", "sq_local"):
                     a[1] += 1
     sq_lines.append(f"== {run} ==")
     for k, cs in sorted(acc.items()):
-        if not any(t in k for t in ("k_resample_staged", "k_sat_fast", "k_circle_walk", "k_flat_walk")):
+        if not any(t in k for t in ("k_resample_staged", "k_sat_fast", "k_circle_walk", "k_flat_walk", "k_emit_queue")):
             continue
         sq_lines.append(k)
         for c, (sv, n) in sorted(cs.items()):

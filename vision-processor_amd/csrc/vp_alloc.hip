@@ -68,11 +68,13 @@ extern "C" int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t byt
 // consecutive allocations = 33 GB all fast, ~30 % of 100 overall) and leaves read streams untouched (6.7-6.9 TB/s everywhere).  The SAT pass writes
 // its table once per launch: 608 us into a fast allocation, 650-705 us into a slow one.  So: allocate candidates WITHOUT freeing (a freed block is
 // handed out again by the next hipMalloc), probe each, keep the fastest, free the rest.
-// When to stop is decided RELATIVE to what the search has seen (no device-specific rate): once `count` blocks lie within 4 % of the best seen AND
-// either a block at least 10 % slower than the best has shown that there are two populations on this device, or sixteen candidates all look alike (one
-// population, or 0.7^16 = 0.3 % of bad luck on a device where 30 % of the blocks are fast: nothing to choose).  The search never holds more than "placement_max_mib" (vp_ctx_tune; 0 = half of the free memory) at once: a second
-// context or process on the same GPU keeps room.  VpPlacement.selected says how it ended: 1 = criterion met, 2 = budget (candidates or bytes) or memory
-// ran out first and the best blocks seen were kept.
+// When to stop: a block counts as fast when its zero-fill rate reaches 0.70 of the READ-stream rate measured on the first candidate (reads do not
+// depend on the placement: 6.5-6.9 TB/s; fast blocks write at 0.74-0.81 of that, slow ones at 0.57-0.66) -- a ratio of two measurements of this device,
+// not an MI355X constant.  The search ends once `count` blocks are fast, or once sixteen candidates lie within 6 % of each other (one population:
+// nothing to choose).  [A rule relative to the best block seen was tried first and stopped inside the slow population, which is itself 15 % wide.]
+// It never holds more than "placement_max_mib" (vp_ctx_tune; 0 = half of the free memory) at once: a second context or process on the same GPU keeps
+// room.  VpPlacement.selected says how it ended: 1 = criterion met, 2 = budget (candidates or bytes) or memory ran out first and the best blocks seen
+// were kept.
 int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info) {
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	for(int i = 0; i < count; i++) dptrs[i] = nullptr;
@@ -93,6 +95,8 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 	size_t spend = free_b / 2; // never hold more than half of what is free while searching
 	if(ctx->tune.placement_max_mib > 0) spend = std::min(spend, (size_t)ctx->tune.placement_max_mib << 20);
 	bool met = false;
+	float fast_gbs = 0.f; // 0.70 x the read-stream rate of this device, measured on the first candidate
+	int n_fast = 0;
 	while((int)cands.size() < (select ? budget : count)) {
 		if(select && (int)cands.size() >= count && (cands.size() + 1) * bytes > spend) break;
 		void* p = nullptr;
@@ -113,18 +117,32 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 			}
 		}
 		const float gbs = us > 0.f ? (float)((double)bytes / us * 1e-3) : 0.f;
-		cands.push_back({p, gbs});
-		if(select && (int)cands.size() >= count) {
-			float best = 0.f, worst = gbs;
-			for(const Cand& c : cands) {
-				best = std::max(best, c.gbs);
-				worst = std::min(worst, c.gbs);
+		if(select && cands.empty()) {
+			float rus = 0.f;
+			const int rc = vp_probe_stream_impl(ctx, 0, p, bytes & ~size_t(15), 0, 3, &rus);
+			if(rc != VP_OK) {
+				(void)hipFree(p);
+				return rc;
 			}
-			int near_best = 0;
-			for(const Cand& c : cands) near_best += c.gbs >= 0.96f * best;
-			if(near_best >= count && (worst <= 0.90f * best || cands.size() >= 16)) {
+			fast_gbs = rus > 0.f ? 0.70f * (float)((double)bytes / rus * 1e-3) : 0.f;
+		}
+		cands.push_back({p, gbs});
+		if(select) {
+			n_fast += fast_gbs > 0.f && gbs >= fast_gbs;
+			if(n_fast >= count) {
 				met = true;
 				break;
+			}
+			if(cands.size() >= 16) { // one population?
+				float best = 0.f, worst = gbs;
+				for(const Cand& c : cands) {
+					best = std::max(best, c.gbs);
+					worst = std::min(worst, c.gbs);
+				}
+				if(worst >= 0.94f * best) {
+					met = true;
+					break;
+				}
 			}
 		}
 	}
