@@ -329,7 +329,10 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 //   * wave 3, which has no carry chain, turns the sub-segment totals into their exclusive prefix while waves 0-2 look back.
 // LDS image of a tile: raw[rows][72] dwords = [4 - O pad | O halo | 64 interior | O halo | pad], rows = 64 + 2 O.
 // RAG: width not a multiple of 64 (the last tile column clamps / masks per pixel).  GD: also write the F32 gradDot view.
-template<int O, int WPC, bool GD, bool RAG>
+// LDC: the tile loads use the default cache policy instead of nt.  A launch whose flat fits the Infinity Cache beside its table (<= 112 MiB: 8 frames of
+// cfg2) reads what the resampling kernel has just written: cached loads take 4.4 % off the whole frame at 8 frames and 3.5 % at one, nothing from 16 on
+// (interleaved A/B, profiles/r04_sat_cache_policy.json); cached STORES lose at every size (+ 7 % at 128 frames), so the table is always streamed out.
+template<int O, int WPC, bool GD, bool RAG, bool LDC = false>
 __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restrict__ in, int32_t* __restrict__ sat, float* __restrict__ gd_out, const TiledArgs a_in) {
 	TiledArgs a = a_in; // ticket_base and epoch are filled in below
 	static_assert(O >= 1 && O <= 4 && TW == 64 && TH == 64, "fast path geometry");
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	auto clamp_row = [&](int Y0, int row) { return (uint32_t)vp_clampi(Y0 - O + row, 0, h - 1); };
 	auto tile_load = [&](int P, int X0, int Y0, int c4, int r16) -> v4u {
 		const uint32_t rowoff = clamp_row(Y0, min(r16 + 16 * P, ROWS - 1)) * row_bytes;
-		if(!RAG || X0 + TW <= w) return (v4u)__builtin_amdgcn_raw_buffer_load_b128(rs_flat, rowoff + 16u * (uint32_t)c4, (uint32_t)X0 * 4u, 2); // aux 2 = nt: read once
+		if(!RAG || X0 + TW <= w) return (v4u)__builtin_amdgcn_raw_buffer_load_b128(rs_flat, rowoff + 16u * (uint32_t)c4, (uint32_t)X0 * 4u, LDC ? 0 : 2); // aux 2 = nt: read once
 		// the last tile column of a width that is not a multiple of 64 (workgroup-uniform): columns past the image take the edge
 		// pixel, clamp-to-edge as gradientDot.cl:20 reads them
 		v4u v;
@@ -754,6 +757,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	if(fast) {
 		const size_t lds2 = sizeof(int) * ((size_t)(TH + 2 * o) * (TW + 8) + 32 * TW + TH + TW + TH + 8);
 		const uint32_t* fin = reinterpret_cast<const uint32_t*>(in);
+		const bool cached_loads = (size_t)w * h * 4 * batch <= (size_t(112) << 20); // flat still sits in the Infinity Cache (see LDC)
 #define VP_FAST2(OO) \
 		do { \
 			if((w % TW) != 0) { \
@@ -761,6 +765,7 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 				else k_sat_fast2<OO, 5, false, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 			} else if(graddot_out) k_sat_fast2<OO, 5, true, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 			else if(wpc == 6) k_sat_fast2<OO, 6, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
+			else if(cached_loads) k_sat_fast2<OO, 5, false, false, true><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 			else k_sat_fast2<OO, 5, false, false><<<grid, 256, lds2, s>>>(fin, sat, graddot_out, a); \
 		} while(0)
 		if(o == 1) VP_FAST2(1);
