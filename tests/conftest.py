@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _torch_tensors_are_complete_before_the_library_sees_them(request):
+    """GPU tests fill fresh torch tensors on torch's stream and hand them to calls on the library's own (non-blocking) streams: the Python binding then
+    waits for torch's stream before every such call (capi.FENCE_TORCH).  Found by a test whose 0xAB fill landed AFTER vp_records_compact had written
+    its slot headers once vp_frame had become faster; the C ABI itself makes no promise about other streams, as no HIP library does."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import cases
+        cases.vp.load_capi().FENCE_TORCH = True
+    yield
+
+
 @pytest.fixture(scope="session")
 def port():
     import oracle as O

@@ -79,6 +79,13 @@ def lib():
     return _lib
 
 
+# The library's own streams are non-blocking: nothing orders them against the stream torch fills a fresh tensor on (torch.zeros / torch.full are kernels
+# on torch's current stream).  A caller that hands such a tensor to a call on a library-owned stream must have synchronised first -- as with any two HIP
+# streams.  The GPU tests set FENCE_TORCH (tests/conftest.py): every torch tensor handed over is then complete before the call is made.  bench.py and
+# the tools leave it off (they synchronise where they must; a host-side wait per call would distort their timings).
+FENCE_TORCH = False
+
+
 def _ptr(x):
     """Raw device pointer of a torch tensor / int / None."""
     if x is None:
@@ -86,6 +93,9 @@ def _ptr(x):
     if isinstance(x, int):
         return C.c_void_p(x)
     if hasattr(x, "data_ptr"):
+        if FENCE_TORCH and getattr(x, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream().synchronize()
         return C.c_void_p(x.data_ptr())
     raise TypeError(type(x))
 
