@@ -44,17 +44,19 @@ def test_two_ranks_on_one_device_gather_the_oracles_detection_packets(tmp_path, 
     check_gathered_packets(open(dump, "rb").read(), 2, feeds, r["detect"]["packet_slot_bytes"], warmup + steps)
 
 
-def test_two_ranks_on_one_device_gather_the_oracles_records(tmp_path):
-    """The same pipeline without the CPU stage: every rank's compact record block (vp_records_compact straight into the gather block) arrives at both
-    ranks; rank 1's receive area holds, for every feed of both ranks, the oracle's counters and raster-sorted records + pixel indices."""
+@pytest.mark.parametrize("ranks,feeds", [(2, 3), (4, 2)])
+def test_two_ranks_on_one_device_gather_the_oracles_records(tmp_path, ranks, feeds):
+    """The same pipeline without the CPU stage, with two and with four ranks (driver threads) on the one device: every rank's compact record block
+    (vp_records_compact straight into the gather block) arrives at every rank; the last rank's receive area holds, for every feed of the first two
+    ranks, the oracle's counters and raster-sorted records + pixel indices, and the program's --verify covers all ranks byte for byte."""
     f = cases.vp.feeds
-    feeds, steps, warmup, cap = 3, 5, 2, 192
+    steps, warmup, cap = 5, 2, 192
     dump = str(tmp_path / "records.bin")
-    r, _ = run_feeds("--gpus", 2, "--same-device", feeds, steps, warmup, "--verify", "--dump", dump, "--cap", cap)
-    assert r["gather_verified"] is True and r["block"] == "compact records" and r["truncated_slots_last_step"] == 0 and r["same_device"] is True
+    r, _ = run_feeds("--gpus", ranks, "--same-device", feeds, steps, warmup, "--verify", "--dump", dump, "--cap", cap)
+    assert r["gpus"] == ranks and r["gather_verified"] is True and r["block"] == "compact records" and r["truncated_slots_last_step"] == 0 and r["same_device"] is True
     blob = np.frombuffer(open(dump, "rb").read(), np.uint8)
     block = r["record_bytes_per_gpu"]
-    assert blob.size == 2 * block
+    assert blob.size == ranks * block
     slot = f.compact_slot_bytes(cap)
     off_i = (16 + 22 * cap + 3) & ~3
     cfg, mm = CFG, CFG.max_matches
