@@ -392,7 +392,7 @@ __device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
 // Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
 // sample directly (bayer4_eval); results are identical either way.
 // VARIANT 0: BILINEAR_RTZ, box staged as bytes; 1: BILINEAR_RTZ, box staged as floats (default); 2: NEAREST, box staged as bytes.
-template<int LAYOUT, int VARIANT>
+template<int LAYOUT, int VARIANT, bool NTS>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch, int xcd_map) {
 	__shared__ uint32_t stage[RESAMPLE_FPT][STAGE_DW];
@@ -452,6 +452,11 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					(int)((size_t)(f1 - f0) * strips.frame_words * 4), 0x00020000);
 			const uint32_t fb_raw = (uint32_t)src_frame_bytes, fb_flat = (uint32_t)(npx * 4), fb_strip = (uint32_t)(strips.frame_words * 4);
 			const uint32_t voff_out = 4u * (uint32_t)(min(gy, fh - 1) * fw + min(gx, fw - 1));
+			// NTS: flat goes out non-temporal when the launch's flat is far larger than the Infinity Cache (the SAT pass will read it from HBM anyway, and what
+			// the resampling kernel leaves dirty in the caches is written back during that pass): - 1.4 % per 128-frame vp_frame, - 1.5 % at 64; cached for
+			// launches that fit (the SAT pass then reads flat from the cache: nt costs + 2.4..8 % at 8 frames).  A template parameter: as a run-time branch
+			// it cost more than half of what it gains (profiles/r04_sat_cache_policy.json).
+			auto store_flat = [&](uint32_t px4, uint32_t soff) { __builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, soff, NTS ? 2 : 0); };
 			// halo-strip destinations of this pixel (emit_strip(), hoisted out of the frame loop)
 			const int xm = gx & 63, tb = gx >> 6;
 			const uint32_t so = (uint32_t)strips.o, shp = (uint32_t)strips.hp; // VpStrips::rec in 32-bit arithmetic (frame_words * 4 < 2 GiB)
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					bayer4_rows(window(io0), window(io1), g.xa, g.xb, g.yb, p[2], p[3]);
 					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
 					// (lanes past the right/bottom edge hold the clamped pixel's own value: the duplicate store is harmless)
-					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
+					store_flat(px4, (uint32_t)j * fb_flat);
 					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
 				}
 			};
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					p[3] = bilin(t30[o], t31[o], t32[o], t33[o], g.xb, g.yb);
 					if(j + 1 < nf) put((j + 1) & 1, pre[j + 1 < RESAMPLE_FPT ? j + 1 : j]);
 					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
-					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
+					store_flat(px4, (uint32_t)j * fb_flat);
 					sslot[(j & 1) * 32] = px4;
 					if(j > 0) flush(j - 1);
 					__syncthreads(); // frame j+1 is staged; everybody is done reading frame j's buffer before frame j+2 overwrites it
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					const uint32_t* st = stage[j];
 					const uint32_t tea = (st[iea] >> sa) & 0xFF, teb = (st[ieb] >> sb) & 0xFF, toa = (st[ioa] >> sa) & 0xFF, tob = (st[iob] >> sb) & 0xFF;
 					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(tea, teb / 2 + toa / 2, tob) : drgb_pack(teb, tea / 2 + tob / 2, toa);
-					__builtin_amdgcn_raw_buffer_store_b32(px4, rs_flat, voff_out, (uint32_t)j * fb_flat, 0);
+					store_flat(px4, (uint32_t)j * fb_flat);
 					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
 				}
 			};
@@ -853,7 +858,12 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 		// XCD-contiguous tile bands for large frames (measured at 2048x1536: HBM reads 1.38 -> 0.60 GB per 128 frames, time unchanged;
 		// at 640x480 the bands unbalance the XCDs: 87 -> 99 us, so small grids keep the plain mapping).  vp_ctx_tune "resample_xcd_bands" forces it.
 		const int xcd_map = ctx->tune.resample_xcd_bands >= 0 ? ctx->tune.resample_xcd_bands : (grid.x * grid.y >= 4096u);
-#define VP_RST(L, V) k_resample_staged<L, V><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map)
+		const bool flat_nt = (size_t)fw * fh * 4 * batch > (size_t(112) << 20); // see store_flat in k_resample_staged
+#define VP_RST(L, V) \
+		do { \
+			if(flat_nt) k_resample_staged<L, V, true><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map); \
+			else k_resample_staged<L, V, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map); \
+		} while(0)
 		if(layout == VP_LAYOUT_RGGB) {
 			if(variant == 2) VP_RST(VP_LAYOUT_RGGB, 2);
 			else if(variant == 1) VP_RST(VP_LAYOUT_RGGB, 1);
