@@ -97,7 +97,7 @@ const char* vp_device_name(VpContext* ctx);
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "tail_emit_kernel" 0 / 1 (default 1: the walkers' survivors become records in a second
  *   launch, one workgroup per frame; 0: inside the walker), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
- *   write the dense halo strips the tiled SAT pass reads), "placement_max_mib" n (default 0: MiB a placement search may hold at once, 0 = half of the free memory), "placement_candidates" 0..256 (default 48: blocks vp_malloc_device_placed may probe per
+ *   write the dense halo strips the tiled SAT pass reads), "placement_max_mib" n (default 0: MiB a placement search may hold at once, 0 = half of the free memory), "placement_candidates" 0..256 (default 96: blocks vp_malloc_device_placed may probe per
  *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 / 2 (default 0; 1: vp_frame captures the launches of a (stream, parameters, batch,
  *   buffers) call into a hipGraph when the call follows itself on the stream and replays the graph from then on; a stream whose state belongs to another
  *   tuple -- another launch shape, another geometry -- takes the ordinary path, which repairs it; calls with stage events enabled or debug views always
@@ -128,7 +128,7 @@ int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int wri
 /* Placement-checked device memory.  On MI355X a large hipMalloc block takes write streams at one of two rates for as long as it lives (4.95-5.4 or
  * 3.8-4.4 TB/s zero-fill; reads are not affected), decided by where the allocation landed.  The reference allocates its images once and keeps them
  * (OpenCL::acquire pool, opencl.cpp:108-122; CLArray, opencl.cpp:137-159), so the draw is made once: vp_malloc_device_placed allocates up to
- * "placement_candidates" (vp_ctx_tune, default 48) blocks without freeing, times a zero-fill of each (vp_probe_stream), hands out the `count`
+ * "placement_candidates" (vp_ctx_tune, default 96) blocks without freeing, times a zero-fill of each (vp_probe_stream), hands out the `count`
  * fastest (dptrs[0] the fastest) and frees the rest.  It stops early once `count` blocks write at 0.70 or more of the read-stream rate it measured on
  * the first candidate (a ratio of two measurements of this device, not an MI355X constant: fast blocks reach 0.74-0.81, slow ones 0.57-0.66), or once
  * sixteen candidates lie within 6 % of each other; it never holds more than half of the free device memory, or "placement_max_mib" MiB (vp_ctx_tune,
