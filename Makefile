@@ -55,7 +55,7 @@ $(PKG)/host/vp_frame_loop: $(FACADE_SRCS) $(wildcard $(PKG)/host/*.h) $(PKG)/lib
 	g++ $(CXXFLAGS) -o $@ $(FACADE_SRCS) -L$(PKG) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
 
 # many feeds on one GPU, C++ on the C ABI alone (vp_frame + read-back + vph_detect_batch, CPU stage overlapped with the next step)
-$(PKG)/host/vp_feeds: $(PKG)/host/feeds_main.cpp $(PKG)/host/feeds_multi.cpp include/vp_hip.h include/vp_multi.h include/vp_host.h $(PKG)/libvp_hip.so $(FEEDS_MULTI_DEPS) $(PKG)/libvp_host.so
+$(PKG)/host/vp_feeds: $(PKG)/host/feeds_main.cpp $(PKG)/host/feeds_multi.cpp $(PKG)/host/feeds.h include/vp_hip.h include/vp_multi.h include/vp_host.h $(PKG)/libvp_hip.so $(FEEDS_MULTI_DEPS) $(PKG)/libvp_host.so
 	g++ $(CXXFLAGS) $(if $(FEEDS_MULTI_SRC),-DVP_HAVE_MULTI) -o $@ $(PKG)/host/feeds_main.cpp $(FEEDS_MULTI_SRC) -L$(PKG) $(FEEDS_MULTI_LIBS) -lvp_hip -lvp_host -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 oracle:

@@ -688,6 +688,10 @@ def main():
             "blobs_per_frame": float(np.minimum(cnt[:, 0], mm).mean()),
             "placement": dict(slab.placement, note="zero-fill GB/s of the blocks vp_frame_buffers_create kept for the table and flat, of the candidates it probed"),
         }
+        for k, pl in slab.placement.items():  # a search that ran out of budget kept a slow block: say so where the number is read
+            if pl.get("warning"):
+                out.setdefault("warnings", []).append(f"placement[{k}]: {pl['warning']}")
+                print(f"[WARN] bench.py: placement[{k}]: {pl['warning']}", file=sys.stderr)
         # every stage against the same HBM roofline, on its own algorithmic bytes per flat pixel: raw sensor byte + flat
         # written (resampling), flat read + table written (SAT pass), table read (circle + blobList), flat read (local variant)
         per_px = {"raw2quad+resampling": 4.0 + cfg.qw * cfg.qh * (3.0 if cfg.layout == vp.configs.BGR else 4.0) / cfg.n_flat, "gradientDot+sat": 8.0, "satBlobCenter+blobList": 4.0,

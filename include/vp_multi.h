@@ -39,7 +39,7 @@ size_t vp_packet_layout(int batch, int slot_bytes);
 /* One communicator per device (ncclCommInitAll over devices[0..n)), one gather stream per device, n_slots (1..4) send / receive
  * buffer pairs per device so that the gather of step k runs beside the kernels of step k + 1. */
 int vp_gather_create(int n_devices, const int* devices, size_t bytes_per_device, int n_slots, VpGather** out);
-/* TEST-ONLY constructor: n_ranks ranks that all live on ONE device, each with its own gather stream, send / receive blocks and events;
+/* TEST-ONLY, UNSTABLE (not part of the supported ABI: a deployment never calls it, and it may change or go away without notice) constructor: n_ranks ranks that all live on ONE device, each with its own gather stream, send / receive blocks and events;
  * vp_gather_start then performs the all-gather as n x n device-to-device copies on the gather streams behind the same ready / done events.  No RCCL.
  * Never selected implicitly and never a fallback of vp_gather_create (which refuses a device listed twice): it exists so that the N > 1 host pipeline
  * (vp_feeds --gpus N --same-device: driver threads, rendezvous, last-arriver gather, slot reuse, end-of-run drain) can be executed on a one-GPU box. */

@@ -14,14 +14,22 @@ def pytest_configure(config):
 
 
 @pytest.fixture(autouse=True)
-def _torch_tensors_are_complete_before_the_library_sees_them(request):
+def _torch_tensors_are_ordered_before_the_library_sees_them(request):
     """GPU tests fill fresh torch tensors on torch's stream and hand them to calls on the library's own (non-blocking) streams: the Python binding then
-    waits for torch's stream before every such call (capi.FENCE_TORCH).  Found by a test whose 0xAB fill landed AFTER vp_records_compact had written
-    its slot headers once vp_frame had become faster; the C ABI itself makes no promise about other streams, as no HIP library does."""
-    if request.node.get_closest_marker("gpu") is not None:
-        import cases
-        cases.vp.load_capi().FENCE_TORCH = True
-    yield
+    orders torch's stream (of the tensor's device) before every such call with a device-side event (capi.FENCE_TORCH -> vp_stream_wait_for; no host wait,
+    so the suite still submits its calls back to back as bench.py and real callers do).  Found by a test whose 0xAB fill landed AFTER vp_records_compact
+    had written its slot headers once vp_frame had become faster; the C ABI itself makes no promise about other streams, as no HIP library does."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import cases
+    capi = cases.vp.load_capi()
+    capi.FENCE_TORCH = True
+    try:
+        yield
+    finally:
+        capi.FENCE_TORCH = False
+        del capi._pending[:]
 
 
 @pytest.fixture(scope="session")

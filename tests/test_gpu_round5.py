@@ -1,0 +1,188 @@
+"""GPU tests added in round 5, all through the C ABI.
+
+  * vp_stream_wait_for / vp_stream_release_to: the device-side edges between a context's own (non-blocking) streams and streams the library does not own
+    -- the cl::Event of OpenCL::run (opencl.h:76-86) as a dependency instead of a host wait.
+  * a refused graph capture is bounded (eight bodies in a row, then the tuple stays on the ordinary path) and leaves no stale vp_last_error behind.
+  * the placement search keeps to its footprint cap and says when it ran out of budget.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return cases.vp.load_capi(), torch
+
+
+def oracle_frame(port, cfg, raw, mm):
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    return port.frame(raw, cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                      cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+
+
+def test_stream_edges_order_a_library_stream_against_foreign_streams(env, port):
+    """A producer stream the library does not own is kept busy for tens of milliseconds and only THEN copies the sensor frame into the buffer vp_frame
+    reads; a consumer stream reads the results.  With the FENCE_TORCH helper of the tests switched off, the only things ordering the three streams are
+    vp_stream_wait_for (producer -> library stream) and vp_stream_release_to (library stream -> consumer): no host synchronisation anywhere between
+    the first enqueue and the final wait.  Without the first edge vp_frame would run on the zero-filled buffer, without the second the consumer would
+    copy unfinished arrays; the results must be the oracle's.  Repeated with a fresh frame: the edges are per call, not a one-off."""
+    capi, torch = env
+    cfg, mm = cfgs.T_MID, cfgs.T_MID.max_matches
+    capi.FENCE_TORCH = False  # this test orders its streams itself (the autouse fixture restores nothing it did not set: it resets the flag afterwards)
+    ctx = capi.Context(0, n_streams=2)
+    try:
+        prod, cons = torch.cuda.Stream(), torch.cuda.Stream()
+        p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+        d_raw = torch.zeros(cfg.sensor_shape, dtype=torch.uint8, device="cuda")
+        flat = torch.zeros((cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+        sat = torch.zeros((cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
+        m = torch.zeros(mm * 22, dtype=torch.uint8, device="cuda")
+        idx = torch.zeros(mm, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(3, dtype=torch.int32, device="cuda")
+        busy = torch.randn(4096, 4096, device="cuda")
+        torch.cuda.synchronize()
+        for rnd, stream in ((0, 1), (1, 0), (2, 1)):
+            raw = cfg.synth(7700 + rnd)
+            h_raw = torch.from_numpy(raw).pin_memory()
+            with torch.cuda.stream(prod):
+                acc = busy
+                for _ in range(24):  # ~ tens of ms of matrix products ahead of the copy
+                    acc = acc @ busy * 1e-3
+                d_raw.copy_(h_raw, non_blocking=True)
+            ctx._ck(ctx.l.vp_stream_wait_for(ctx.h, stream, C.c_void_p(prod.cuda_stream)))
+            ctx.frame(p, d_raw, 1, flat, sat, m, cnt, idx=idx, stream=stream)
+            ctx._ck(ctx.l.vp_stream_release_to(ctx.h, stream, C.c_void_p(cons.cuda_stream)))
+            with torch.cuda.stream(cons):
+                got = [t.to("cpu", non_blocking=False) for t in (cnt, idx, m)]
+            # the producer may not overwrite d_raw for the next round before this round's vp_frame has read it: the reverse edge
+            ctx._ck(ctx.l.vp_stream_release_to(ctx.h, stream, C.c_void_p(prod.cuda_stream)))
+            wm, widx, wcnt = oracle_frame(port, cfg, raw, mm)
+            assert np.array_equal(got[0].numpy(), wcnt), (rnd, got[0].numpy(), wcnt)
+            n = min(int(wcnt[0]), mm)
+            gm, gi = capi.sorted_blobs(got[2].numpy(), got[1].numpy().view(np.uint32), got[0].numpy(), mm)
+            assert n >= 20 and np.array_equal(gi, widx) and gm.tobytes() == wm.tobytes(), rnd
+            del acc
+        # same stream on both sides (an adopted stream is ordered with itself): a no-op, not an error; bad stream indices are refused
+        assert ctx.l.vp_stream_wait_for(ctx.h, 5, C.c_void_p(prod.cuda_stream)) != 0
+        ctx.sync()
+    finally:
+        ctx.close()
+    a = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
+    try:
+        a._ck(a.l.vp_stream_wait_for(a.h, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        a._ck(a.l.vp_stream_release_to(a.h, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    finally:
+        a.close()
+
+
+def test_the_test_fence_is_a_device_side_edge(env):
+    """capi.FENCE_TORCH (what the autouse fixture of tests/conftest.py switches on) must order torch's stream before a call on a library stream without
+    a host wait: a 0xAB fill queued behind a long kernel on torch's stream, handed to vp_memset_device on a library stream at once, must lose to it."""
+    capi, torch = env
+    assert capi.FENCE_TORCH is True
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        busy = torch.randn(4096, 4096, device="cuda")
+        for _ in range(3):
+            acc = busy
+            for _ in range(16):
+                acc = acc @ busy * 1e-3
+            t = torch.full((1 << 20,), 0xAB, dtype=torch.uint8, device="cuda")  # queued behind the products on torch's stream
+            ctx.memset(t, 0x11, t.numel())                                      # library stream: must come after the fill
+            ctx.sync()
+            torch.cuda.synchronize()
+            assert int(t.min()) == 0x11 and int(t.max()) == 0x11
+            del acc
+        assert not capi._pending
+    finally:
+        ctx.close()
+
+
+def test_a_capture_whose_body_keeps_failing_stops_being_attempted(env, port):
+    """frame_graph = 2 (no pre-flight), two launch shapes taking turns on ONE stream: every second sighting of a tuple follows the OTHER shape, so every
+    capture meets a SAT-state reset and is refused and undone.  Round 4 ran the launch sequence twice on every such call for ever; now eight refused
+    bodies in a row put the tuple on the ordinary path for good (2 x 8 refusals in total, however long the alternation lasts), the ordinary retry that
+    follows a refusal leaves vp_last_error empty, and every result is still the oracle's."""
+    capi, torch = env
+    a = cfgs.T_MID
+    b = a.with_(name=a.name + "_704x448", fw=704, fh=448)
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        ctx.tune("frame_graph", 2)
+        st = {}
+        for k, (c, B) in {"A": (a, 2), "B": (b, 3)}.items():
+            mm = c.max_matches
+            raws = [c.synth(8100 + 7 * j + (k == "B")) for j in range(B)]
+            st[k] = dict(cfg=c, B=B, raws=raws, raw=torch.from_numpy(np.stack(raws)).cuda(), flat=torch.zeros((B, c.fh, c.fw, 4), dtype=torch.uint8, device="cuda"),
+                         sat=torch.zeros((B, c.fh, c.fw), dtype=torch.int32, device="cuda"), m=torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda"),
+                         idx=torch.zeros((B, mm), dtype=torch.int32, device="cuda"), cnt=torch.zeros((B, 3), dtype=torch.int32, device="cuda"),
+                         p=capi.frame_params(c, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER))
+            st[k]["want"] = [oracle_frame(port, c, r, mm) for r in raws]
+        torch.cuda.synchronize()
+        refused_after = []
+        for rnd in range(24):
+            s = st["AB"[rnd & 1]]
+            s["cnt"].fill_(-7)
+            ctx.frame(s["p"], s["raw"], s["B"], s["flat"], s["sat"], s["m"], s["cnt"], idx=s["idx"])
+            refused_after.append(ctx.graph_stats()["refused"])
+            if refused_after[-1] > (refused_after[-2] if rnd else 0):  # this call's capture was refused and the ordinary retry made it good:
+                assert ctx.l.vp_last_error() == b"", (rnd, ctx.l.vp_last_error())  # the refusal's message is not this call's outcome
+            ctx.sync()
+            cnt, mm = s["cnt"].cpu().numpy(), s["cfg"].max_matches
+            for j in range(s["B"]):
+                wm, widx, wcnt = s["want"][j]
+                assert np.array_equal(cnt[j], wcnt), (rnd, j, cnt[j], wcnt)
+                n = min(int(wcnt[0]), mm)
+                assert np.array_equal(s["idx"][j].cpu().numpy().view(np.uint32)[:n], widx) and s["m"][j].cpu().numpy()[:22 * n].tobytes() == wm.tobytes(), (rnd, j)
+        stats = ctx.graph_stats()
+        assert stats["captures"] == 0 and stats["replays"] == 0, stats
+        assert stats["refused"] == 16 and refused_after[-1] == refused_after[-5], (stats, refused_after)  # 8 per tuple, none during the last rounds
+    finally:
+        ctx.close()
+
+
+def test_placement_search_keeps_to_its_cap_and_reports_an_exhausted_budget(env):
+    """vp_malloc_device_placed: with "placement_max_mib" the search holds no more than that at once (candidates <= cap / block size); a search that ends
+    without a fast block reports selected = 2 (bench.py and vp_feeds print that as a warning), one that needs no search reports 0.  The default cap is a
+    quarter of the device: asked for 1 GiB blocks it can never probe more than total / 4 GiB of them."""
+    capi, torch = env
+    ctx = capi.Context(0, n_streams=1)
+    lib = ctx.l
+    try:
+        nbytes = 1 << 30
+        free0, total = torch.cuda.mem_get_info()
+
+        def placed(count):
+            ptrs = (C.c_void_p * count)()
+            info = (capi.VpPlacement * count)()
+            ctx._ck(lib.vp_malloc_device_placed(ctx.h, C.c_size_t(nbytes), count, ptrs, info))
+            out = [info[i].as_dict() | {"raw_selected": int(info[i].selected)} for i in range(count)]
+            for q in ptrs:
+                ctx.free(q)
+            return out
+
+        ctx.tune("placement_max_mib", 3 * 1024)  # room for three 1 GiB candidates
+        ctx.tune("placement_candidates", 64)
+        r = placed(1)[0]
+        assert 1 <= r["candidates"] <= 3, r
+        assert r["raw_selected"] in (1, 2) and (("warning" in r) == (r["raw_selected"] == 2)), r
+        ctx.tune("placement_max_mib", 0)
+        r = placed(2)
+        assert all(2 <= x["candidates"] <= max(2, total // 4 // nbytes) for x in r), (r, total)
+        ctx.tune("placement_candidates", 0)  # take what hipMalloc gives
+        r = placed(1)[0]
+        assert r["raw_selected"] == 0 and r["candidates"] == 1 and "warning" not in r, r
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 >= free0 - (64 << 20), (free0, free1)  # every candidate went back
+    finally:
+        ctx.close()

@@ -42,8 +42,11 @@ class VpPlacement(C.Structure):
     _fields_ = [("write_gbs", C.c_float), ("best_gbs", C.c_float), ("worst_gbs", C.c_float), ("candidates", C.c_int32), ("selected", C.c_int32)]
 
     def as_dict(self):
-        return {"write_gbs": round(self.write_gbs, 1), "best_gbs": round(self.best_gbs, 1), "worst_gbs": round(self.worst_gbs, 1), "candidates": int(self.candidates),
-                "selected": bool(self.selected), "search": {0: "none", 1: "criterion met", 2: "budget exhausted"}.get(int(self.selected), "?")}
+        d = {"write_gbs": round(self.write_gbs, 1), "best_gbs": round(self.best_gbs, 1), "worst_gbs": round(self.worst_gbs, 1), "candidates": int(self.candidates),
+             "selected": bool(self.selected), "search": {0: "none", 1: "criterion met", 2: "budget exhausted"}.get(int(self.selected), "?")}
+        if int(self.selected) == 2:  # the best block seen was kept although no candidate reached the write rate of a fast block: a run on it is a slow draw, not the kernel
+            d["warning"] = "placement search ran out of candidates, bytes or memory before a fast block turned up: expect the SAT pass 5-15 % slower than on a fast block"
+        return d
 
 
 VIEW_PLANES, VIEW_GRADDOT, VIEW_BLOBCENTER = 1, 2, 4
@@ -62,6 +65,52 @@ class VpError(RuntimeError):
 _lib = None
 
 
+class _Fenced:
+    """A C entry point behind FENCE_TORCH: torch tensors handed to it through _ptr() are ordered before the call on the DEVICE (vp_stream_wait_for on the
+    tensor's own device's current torch stream: one event, no host wait), so the calls themselves still go out back to back and asynchronously, as bench.py,
+    the tools and real callers issue them.  Attribute access (restype / argtypes) goes to the ctypes function."""
+    __slots__ = ("_f", "_c")
+
+    def __init__(self, f, cdll):
+        object.__setattr__(self, "_f", f)
+        object.__setattr__(self, "_c", cdll)
+
+    def __getattr__(self, k):
+        return getattr(self._f, k)
+
+    def __setattr__(self, k, v):
+        setattr(self._f, k, v)
+
+    def __call__(self, *a):
+        if _pending:
+            tensors = list(_pending)
+            _pending.clear()
+            # every stage entry is (ctx, stream, ...); entries without a stream take no tensors
+            if len(a) >= 2 and isinstance(a[1], int):
+                import torch
+                seen = set()
+                for t in tensors:
+                    sp = torch.cuda.current_stream(t.device).cuda_stream
+                    if (t.device.index, sp) in seen:
+                        continue
+                    seen.add((t.device.index, sp))
+                    rc = self._c.vp_stream_wait_for(a[0], a[1], C.c_void_p(sp))
+                    if rc != VP_OK:
+                        raise VpError(rc, self._c.vp_last_error().decode())
+        return self._f(*a)
+
+
+class _Lib:
+    """libvp_hip.so; with FENCE_TORCH set its entry points are wrapped by _Fenced."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_c", cdll)
+
+    def __getattr__(self, name):
+        f = getattr(self._c, name)
+        return _Fenced(f, self._c) if FENCE_TORCH and name.startswith("vp_") and name not in ("vp_last_error", "vp_stream_wait_for") else f
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -70,20 +119,25 @@ def lib():
         # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing it first makes libvp_hip.so bind to
         # that copy instead of pulling /opt/rocm's next to it (two runtimes in one process lose the device).
         import torch  # noqa: F401
-        _lib = C.CDLL(HIP_SO)
-        _lib.vp_last_error.restype = C.c_char_p
-        _lib.vp_device_name.restype = C.c_char_p
-        _lib.vp_device_name.argtypes = [C.c_void_p]
-        _lib.vp_ctx_destroy.restype = None
-        _lib.vp_ctx_destroy.argtypes = [C.c_void_p]
+        c = C.CDLL(HIP_SO)
+        c.vp_last_error.restype = C.c_char_p
+        c.vp_device_name.restype = C.c_char_p
+        c.vp_device_name.argtypes = [C.c_void_p]
+        c.vp_ctx_destroy.restype = None
+        c.vp_ctx_destroy.argtypes = [C.c_void_p]
+        c.vp_stream_wait_for.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        c.vp_stream_release_to.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib = _Lib(c)
     return _lib
 
 
 # The library's own streams are non-blocking: nothing orders them against the stream torch fills a fresh tensor on (torch.zeros / torch.full are kernels
-# on torch's current stream).  A caller that hands such a tensor to a call on a library-owned stream must have synchronised first -- as with any two HIP
-# streams.  The GPU tests set FENCE_TORCH (tests/conftest.py): every torch tensor handed over is then complete before the call is made.  bench.py and
-# the tools leave it off (they synchronise where they must; a host-side wait per call would distort their timings).
+# on torch's current stream).  A caller that hands such a tensor to a call on a library-owned stream must order the two first -- as with any two HIP
+# streams (vp_stream_wait_for, or a synchronisation of its own).  The GPU tests set FENCE_TORCH (tests/conftest.py): every torch tensor handed over is
+# then ordered before the call by a device-side event on the torch stream of the tensor's device.  bench.py and the tools leave it off (they synchronise
+# where they must).
 FENCE_TORCH = False
+_pending = []  # torch tensors _ptr() has seen since the last call went out (FENCE_TORCH only)
 
 
 def _ptr(x):
@@ -94,8 +148,7 @@ def _ptr(x):
         return C.c_void_p(x)
     if hasattr(x, "data_ptr"):
         if FENCE_TORCH and getattr(x, "is_cuda", False):
-            import torch
-            torch.cuda.current_stream().synchronize()
+            _pending.append(x)
         return C.c_void_p(x.data_ptr())
     raise TypeError(type(x))
 

@@ -72,8 +72,8 @@ extern "C" int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t byt
 // depend on the placement: 6.5-6.9 TB/s; fast blocks write at 0.74-0.81 of that, slow ones at 0.57-0.66) -- a ratio of two measurements of this device,
 // not an MI355X constant.  The search ends once `count` blocks are fast, or once sixteen candidates lie within 6 % of each other (one population:
 // nothing to choose).  [A rule relative to the best block seen was tried first and stopped inside the slow population, which is itself 15 % wide.]
-// It never holds more than "placement_max_mib" (vp_ctx_tune; 0 = half of the free memory) at once: a second context or process on the same GPU keeps
-// room.  VpPlacement.selected says how it ended: 1 = criterion met, 2 = budget (candidates or bytes) or memory ran out first and the best blocks seen
+// It never holds more than "placement_max_mib" (vp_ctx_tune; 0 = half of the free memory, at most a quarter of the device) at once and stops while an
+// eighth of the device is still free: a second context or process on the same GPU keeps room.  VpPlacement.selected says how it ended: 1 = criterion met, 2 = budget (candidates or bytes) or memory ran out first and the best blocks seen
 // were kept.
 int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info) {
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -92,13 +92,22 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 	};
 	size_t free_b = 0, total_b = 0;
 	VP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
-	size_t spend = free_b / 2; // never hold more than half of what is free while searching
-	if(ctx->tune.placement_max_mib > 0) spend = std::min(spend, (size_t)ctx->tune.placement_max_mib << 20);
+	// What the search may hold at once: "placement_max_mib", else half of what was free when it started but never more than a quarter of the device
+	// (two searches that start together on one GPU -- two contexts, two processes -- then hold half of it at most between them).  Independently of
+	// that cap the loop below asks the device again before every candidate and stops once the memory free NOW, whoever took the rest, would fall
+	// under a reserve of an eighth of the device: somebody else's hipMalloc must not fail because this search is shopping.
+	size_t spend = std::min(free_b / 2, total_b / 4);
+	if(ctx->tune.placement_max_mib > 0) spend = std::min(free_b / 2, (size_t)ctx->tune.placement_max_mib << 20);
+	const size_t reserve = total_b / 8;
 	bool met = false;
 	float fast_gbs = 0.f; // 0.70 x the read-stream rate of this device, measured on the first candidate
 	int n_fast = 0;
 	while((int)cands.size() < (select ? budget : count)) {
-		if(select && (int)cands.size() >= count && (cands.size() + 1) * bytes > spend) break;
+		if(select && (int)cands.size() >= count) {
+			if((cands.size() + 1) * bytes > spend) break;
+			size_t free_now = 0, t_ = 0;
+			if(hipMemGetInfo(&free_now, &t_) != hipSuccess || free_now < bytes + reserve) break;
+		}
 		void* p = nullptr;
 		if(hipMalloc(&p, bytes) != hipSuccess) {
 			(void)hipGetLastError();

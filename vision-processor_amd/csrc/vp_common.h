@@ -52,7 +52,7 @@ struct VpTuning {
 	int tail_segment_rows = 0;     // circle + detect: image rows per wavefront; 0 = chosen from the launch size (32 / 64 / 128)
 	int frame_graph = 0;           // vp_frame replays a captured hipGraph of its launches for a repeated (stream, parameters, batch, buffers) tuple (2: no pre-flight, see vp_frame.hip)
 	int tail_emit_kernel = 1;      // walkers: records by a second launch from per-frame survivor queues (1, default) or inside the walker (0)
-	int placement_max_mib = 0;     // vp_malloc_device_placed: MiB the search may hold at once (0 = half of the free device memory)
+	int placement_max_mib = 0;     // vp_malloc_device_placed: MiB the search may hold at once (0 = half of the free device memory, at most a quarter of the device; it also stops while an eighth of the device is still free)
 	int placement_candidates = 96; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives); 48 ran
 	                               // out twice in six fresh processes on a box whose fast blocks were scarce (profiles/r04_bench_spread.json); the bytes held stay capped
 };
@@ -63,6 +63,7 @@ struct VpFrameGraph {
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t exec = nullptr;
 	int refused = 0;           // captures the runtime could not make; after three the tuple stays on the ordinary path
+	int refused_bodies = 0;    // consecutive captures whose launch sequence itself failed (a refused repair, a launch error); after eight likewise
 	bool noted = false;        // the fields below hold the stream state the tuple's launches need (recorded after each ordinary call / capture)
 	uint64_t ws_generation = 0, sat_shape = 0;
 	uint32_t sat_tickets = 0;
@@ -95,6 +96,7 @@ struct VpContext {
 };
 
 void vp_set_error(const char* fmt, ...);
+void vp_clear_error(); // a call that succeeded after an internal retry leaves no stale message behind
 
 #define VP_CHECK_HIP(expr)                                                                                     \
 	do {                                                                                                         \

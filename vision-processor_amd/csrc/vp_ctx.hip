@@ -16,6 +16,7 @@ void vp_set_error(const char* fmt, ...) {
 	va_end(ap);
 }
 
+void vp_clear_error() { g_err[0] = 0; }
 extern "C" const char* vp_last_error(void) { return g_err; }
 
 extern "C" int vp_device_count(void) {
@@ -142,6 +143,46 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 		return VP_ERR_INVALID;
 	}
 	return VP_OK;
+}
+
+// ---- ordering against other streams: the cl::Event of OpenCL::run (opencl.h:76-86) as a device-side dependency -------------------------------------
+// The context's own streams are non-blocking: nothing orders them against a stream the caller fills its buffers on, or reads the results on.  Both
+// directions are one event: recorded on the producing stream, waited for by the consuming one; the host never blocks.
+static int stream_edge(VpContext* ctx, hipStream_t producer, int producer_device, hipStream_t consumer, const char* what) {
+	VP_REQUIRE(!(producer == consumer), "%s: both sides are the same stream (already ordered)", what);
+	VP_CHECK_HIP(hipSetDevice(producer_device)); // an event is recorded on a stream of the device it was created on
+	hipEvent_t ev = nullptr;
+	VP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	hipError_t e = hipEventRecord(ev, producer);
+	if(e == hipSuccess) e = hipStreamWaitEvent(consumer, ev, 0);
+	(void)hipEventDestroy(ev); // released by the runtime once the recorded work has completed
+	(void)hipSetDevice(ctx->device);
+	if(e != hipSuccess) {
+		vp_set_error("%s failed: %s", what, hipGetErrorString(e));
+		return VP_ERR_HIP;
+	}
+	return VP_OK;
+}
+static int foreign_stream_device(VpContext* ctx, hipStream_t s, int* dev) {
+	*dev = ctx->device; // the legacy default stream (NULL) belongs to the calling thread's current device: callers pass a real stream for another GPU
+	if(s) VP_CHECK_HIP(hipStreamGetDevice(s, dev));
+	return VP_OK;
+}
+
+extern "C" int vp_stream_wait_for(VpContext* ctx, int stream, void* producer_stream) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(!ctx->capturing[stream], "vp_stream_wait_for: the stream is being captured");
+	if((hipStream_t)producer_stream == ctx->streams[stream]) return VP_OK; // an adopted stream is ordered with itself
+	int dev = 0;
+	VP_TRY(foreign_stream_device(ctx, (hipStream_t)producer_stream, &dev));
+	return stream_edge(ctx, (hipStream_t)producer_stream, dev, ctx->streams[stream], "vp_stream_wait_for");
+}
+
+extern "C" int vp_stream_release_to(VpContext* ctx, int stream, void* consumer_stream) {
+	VP_TRY(vp_check_ctx(ctx, stream));
+	VP_REQUIRE(!ctx->capturing[stream], "vp_stream_release_to: the stream is being captured");
+	if((hipStream_t)consumer_stream == ctx->streams[stream]) return VP_OK;
+	return stream_edge(ctx, ctx->streams[stream], ctx->device, (hipStream_t)consumer_stream, "vp_stream_release_to");
 }
 
 // a raised flag means a bounded look-back wait of the single-pass SAT expired: the results of that launch are invalid

@@ -144,11 +144,18 @@ static int frame_graphed(VpContext* ctx, int stream, const VpFrameParams* p, con
 		(void)hipGetLastError();
 		if(graph) (void)hipGraphDestroy(graph);
 		g->exec = nullptr;
-		if(rc == VP_OK) g->refused++; // the runtime could not capture / instantiate: a property of the tuple; a refused repair (rc != VP_OK) is not
+		// the runtime could not capture / instantiate (rc == VP_OK): a property of the tuple, three strikes.  A body that failed inside the capture -- a
+		// refused repair, which the ordinary call below makes good, or a genuine error that will fail there too -- is counted separately and only while it
+		// repeats: eight in a row (frame_graph = 2 alternating shapes, a persistent launch error) and the tuple stops paying for two bodies per call.
+		if(rc == VP_OK) g->refused++;
+		else if(++g->refused_bodies >= 8) g->refused = 3;
 		ctx->graph_stats[2]++;
 		stream_state_restore(ctx, stream, before);
-		return frame_ordinary(ctx, stream, p, raw, batch, b, g); // sees the stream as it was and repairs it
+		const int rc2 = frame_ordinary(ctx, stream, p, raw, batch, b, g); // sees the stream as it was and repairs it
+		if(rc2 == VP_OK) vp_clear_error(); // the refusal's message ("... inside a graph capture") is not this call's outcome
+		return rc2;
 	}
+	g->refused_bodies = 0;
 	g->graph = graph;
 	graph_note_needs(ctx, stream, g);
 	VP_CHECK_HIP(hipGraphLaunch(g->exec, s)); // (the capture counted this launch's SAT tickets already)

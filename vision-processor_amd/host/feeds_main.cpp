@@ -218,7 +218,22 @@ int main(int argc, char** argv) {
 	if(detect)
 		printf(", \"robots_per_frame\": %.3f, \"balls_per_frame\": %.3f, \"packet_bytes_per_frame\": %.1f, \"rendered\": {\"robots\": %d, \"balls\": %d}", robotsSeen / (double)feeds,
 				ballsSeen / (double)feeds, packetBytes / ((double)feeds * steps), robots, balls);
-	printf(", \"host_ms_per_step\": {\"launch\": %.3f, \"wait_for_gpu\": %.3f, \"cpu_stage\": %.3f}}\n", launchMs / steps, waitMs / steps, stageMs / steps);
+	printf(", \"host_ms_per_step\": {\"launch\": %.3f, \"wait_for_gpu\": %.3f, \"cpu_stage\": %.3f}", launchMs / steps, waitMs / steps, stageMs / steps);
+	{ // where the two buffer sets' tables landed (vp_malloc_device_placed): a search that ran out of budget is a slow draw, not the kernel
+		VpPlacement pl[2];
+		int exhausted = 0;
+		for(int s = 0; s < 2; s++) {
+			CK(vp_frame_buffers_placement(slab[s], &pl[s], nullptr));
+			exhausted += pl[s].selected == 2;
+		}
+		printf(", \"placement\": {\"sat_write_gbs\": [%.0f, %.0f], \"candidates\": [%d, %d]", pl[0].write_gbs, pl[1].write_gbs, pl[0].candidates, pl[1].candidates);
+		if(exhausted) {
+			printf(", \"warning\": \"%d of 2 searches kept the best block seen although none reached the write rate of a fast block\"", exhausted);
+			fprintf(stderr, "[WARN] placement search ran out of candidates, bytes or memory for %d of 2 buffer sets: expect the SAT pass 5-15 %% slower\n", exhausted);
+		}
+		printf("}");
+	}
+	printf("}\n");
 
 	for(VphDetector* d : detectors) vph_detector_destroy(d);
 	for(int s = 0; s < 2; s++) {

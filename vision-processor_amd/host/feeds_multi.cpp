@@ -346,7 +346,19 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 	for(int g = 0; g < N; g++) printf("%s%.0f", g ? ", " : "", dev[g].place[0].write_gbs);
 	printf("], \"candidates\": [");
 	for(int g = 0; g < N; g++) printf("%s%d", g ? ", " : "", dev[g].place[0].candidates + 0);
-	printf("]}");
+	printf("], \"search\": [");
+	int exhausted = 0;
+	for(int g = 0; g < N; g++) {
+		const int sel = dev[g].place[0].selected;
+		exhausted += sel == 2;
+		printf("%s\"%s\"", g ? ", " : "", sel == 1 ? "criterion met" : sel == 2 ? "budget exhausted" : "none");
+	}
+	printf("]");
+	if(exhausted) {
+		printf(", \"warning\": \"%d device(s) kept the best block seen although none reached the write rate of a fast block\"", exhausted);
+		fprintf(stderr, "[WARN] placement search ran out of candidates, bytes or memory on %d device(s): expect the SAT pass 5-15 %% slower there\n", exhausted);
+	}
+	printf("}");
 	if(o.verify) printf(", \"gather_verified\": %s", verified == 1 ? "true" : "false");
 	printf("}\n");
 
