@@ -168,7 +168,7 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
 
         # frames per launch group (one stream): throughput against batching
         sweep = {}
-        for b in (1, 8, 32, B):
+        for b in sorted({1, 8, 32, 128, B}):
             if b > B:
                 continue
             sweep[str(b)] = round(rate(lambda: ctx.frame(params, d_raw, b, flat, sat, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
@@ -177,7 +177,7 @@ def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, 
         # kernel, flat read once, buffers.sat = NULL).  Same blob list bit for bit (tests/test_gpu_round2.py); the headline keeps the SAT pass.
         p_local = capi.frame_params(cfg, sat_variant=capi.SAT_LOCAL, order=params.order)
         local = {}
-        for b in (1, 8, 32, B):
+        for b in sorted({1, 8, 32, 128, B}):
             if b > B:
                 continue
             local[str(b)] = round(rate(lambda: ctx.frame(p_local, d_raw, b, flat, None, matches, counter, idx=idx, stream=0), max(4, min(200, 1024 // b)), b), 1)
@@ -468,7 +468,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step per GPU (one launch group)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (one launch group); 0 = feeds.BENCH_FRAMES_PER_STEP (256)")
     ap.add_argument("--workload", default="cfg2_2048x1536_rggb")
     ap.add_argument("--sat", default="tiled", choices=["tiled", "twopass", "local"], help="tiled = the single-pass SAT the roofline is quoted on (default); twopass = global-recursive comparison; "
                     "local = optional variant without a global table (one fused kernel after resampling)")
@@ -526,7 +526,8 @@ def main():
     cfg = vp.configs.ALL[args.workload]
     if args.sampler == "nearest":  # the other reading of resampling.cl:50: everything below -- kernels, oracle check, CPU baseline -- follows
         cfg = cfg.with_(sampler_mode=vp.configs.SAMPLER_NEAREST)
-    B, mm = args.batch, cfg.max_matches
+    B, mm = args.batch or vp.feeds.BENCH_FRAMES_PER_STEP, cfg.max_matches
+    args.batch = B
     ctx = capi.Context(local_rank, stream_ptr=torch.cuda.current_stream().cuda_stream)
     params = capi.frame_params(cfg, sat_variant={"tiled": capi.SAT_TILED, "twopass": capi.SAT_TWOPASS, "local": capi.SAT_LOCAL}[args.sat],
                                order=capi.ORDER_RASTER if args.order == "raster" else capi.ORDER_ATOMIC)
@@ -541,6 +542,8 @@ def main():
     # placement-checked blocks (vp_frame_buffers_create; --plain-alloc: take what hipMalloc gives, the round-2 behaviour)
     if args.plain_alloc:
         ctx.tune("placement_candidates", 0)
+    elif not rehearse:
+        ctx.tune("placement_max_mib", -1)  # one rank per GPU and nobody else on it: the placement search may hold half of the free memory (default: a quarter of the device, with a reserve)
     slab = ctx.frame_slab(params, B)
     flat, sat, matches, idx, counter = slab.torch_views()
     # what a rank contributes to the per-step gather: the COMPACT records (vp_records_compact: per frame counter[3], n and the n records a host loop
@@ -733,7 +736,7 @@ def main():
         if not args.no_verify:
             # what the timed steps left in the buffers (before the extra measurements reuse them), held to the CPU oracle
             vm, vc = (det["m"][(step_no[0] - 1) & 1], det["c"][(step_no[0] - 1) & 1]) if det is not None else (matches, counter)
-            out["verified"] = verify_against_oracle(cfg, raws, sorted({0, B - 1}), flat, sat, vm, idx, vc, mm)
+            out["verified"] = verify_against_oracle(cfg, raws, sorted({0, B // 2, B - 1}), flat, sat, vm, idx, vc, mm)
         if world == 1 and not args.no_extras and det is None and sat is not None:
             out["extras"] = extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, counter, idx, B)
         if world == 1 and not args.no_cpu_baseline:

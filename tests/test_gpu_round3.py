@@ -3,7 +3,7 @@
   * THE LAUNCH bench.py TIMES: cfg2 (2048x1536 RGGB) x 128 distinct frames in one vp_frame call with the bench's exact parameters
     (VP_SAT_TILED, RASTER order, coordinate map, the adopted torch stream, the feed seeds of feeds.py) -- frames 0, 15, 16, 17 and 127
     (both ends and both sides of a 16-frame resampling group) byte for byte against the CPU oracle: flat, the int32 SAT, counters,
-    sorted records; ALL 128 frames through size-independent properties: the SAT equals the 64-bit 2-D cumulative sum of gradientDot
+    sorted records; ALL frames of the launch (256) through size-independent properties: the SAT equals the 64-bit 2-D cumulative sum of gradientDot
     formed from the kernel's own flat by plain torch integer arithmetic, flat equals what the unstaged per-pixel resampling kernel
     gives, and VP_SAT_LOCAL's records equal VP_SAT_TILED's.  Call sequence replaced: Resources.cpp:151-164 + main.cpp:283-317.
   * BASELINE configs[2] AT ITS OWN SIZE: the same 2048x1536 frames as 8 streams x 8 frames, every stream loaded before anything is
@@ -23,8 +23,8 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 cfgs = cases.cfgs
 CFG = cfgs.CFG2
-B_BENCH = 128          # bench.py --batch default
-ORACLE_FRAMES = (0, 15, 16, 17, 127)
+B_BENCH = cases.vp.feeds.BENCH_FRAMES_PER_STEP  # bench.py --batch default (256 since round 5)
+ORACLE_FRAMES = (0, 15, 16, 17, 127, 128, B_BENCH - 1)
 NS, PER = 8, 8         # configs[2]: 8 streams x 8 frames in flight
 STREAM_ORACLE = {s: s * PER + (3 * s) % PER for s in range(NS)}  # one oracle-checked frame per stream
 
@@ -42,7 +42,7 @@ def env():
 
 @pytest.fixture(scope="module")
 def bench_frames():
-    """The 128 synthetic sensor frames bench.py uploads on rank 0 (feed_seed(0, i)); rendered on host threads (ctypes releases the GIL)."""
+    """The synthetic sensor frames (feeds.BENCH_FRAMES_PER_STEP of them) bench.py uploads on rank 0 (feed_seed(0, i)); rendered on host threads (ctypes releases the GIL)."""
     seeds = [cases.vp.feeds.feed_seed(0, i) for i in range(B_BENCH)]
     with ThreadPoolExecutor(16) as ex:
         return np.stack(list(ex.map(CFG.synth, seeds)))

@@ -179,6 +179,10 @@ def test_placement_search_keeps_to_its_cap_and_reports_an_exhausted_budget(env):
         ctx.tune("placement_max_mib", 0)
         r = placed(2)
         assert all(2 <= x["candidates"] <= max(2, total // 4 // nbytes) for x in r), (r, total)
+        ctx.tune("placement_max_mib", -1)  # "the GPU is mine": half of the free memory, no reserve (bench.py, vp_feeds)
+        r = placed(1)[0]
+        assert r["raw_selected"] in (1, 2) and 1 <= r["candidates"] <= 64, r
+        ctx.tune("placement_max_mib", 0)
         ctx.tune("placement_candidates", 0)  # take what hipMalloc gives
         r = placed(1)[0]
         assert r["raw_selected"] == 0 and r["candidates"] == 1 and "warning" not in r, r

@@ -127,7 +127,7 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 		ctx->tune.frame_graph = value;
 		if(!value) vp_frame_graphs_clear(ctx);
 	} else if(k == "placement_max_mib") {
-		VP_REQUIRE(value >= 0, "vp_ctx_tune: placement_max_mib must not be negative");
+		VP_REQUIRE(value >= -1, "vp_ctx_tune: placement_max_mib: MiB, 0 (default rule) or -1 (this process owns the GPU)");
 		ctx->tune.placement_max_mib = value;
 	} else if(k == "placement_candidates") {
 		VP_REQUIRE(value >= 0 && value <= 256, "vp_ctx_tune: placement_candidates out of range [0,256]");

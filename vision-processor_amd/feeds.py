@@ -10,6 +10,11 @@ from __future__ import annotations
 
 import torch
 
+# Frames per step and GPU of the benchmark launch (bench.py --batch default; tests/test_gpu_round3.py holds this very launch to the oracle).  One launch
+# group of 256 cfg2 feeds: 0.8 GB of sensor frames, 3.2 GB of flat, 3.2 GB of table -- sized for 288 GB of HBM, not for a camera count; measured
+# (profiles/r05_batch_sweep.json): 128 -> 72.7 k frames/s, 256 -> 75.8 k, 512 -> 76.1 k (the SAT pass: 0.665 / 0.696 / 0.672 of 8 TB/s).
+BENCH_FRAMES_PER_STEP = 256
+
 MATCH_BYTES = 22
 HEADER_BYTES = 16  # counter[3] as int32 + 4 bytes padding
 
