@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def _csv_under(name, suffix):
@@ -64,7 +64,7 @@ for variant, names in (("local", ("k_flat_walk",)), ("nearest", ("k_resample_sta
     if os.path.isdir(st):
         shutil.copy(_csv_under(f"stats_{variant}", "kernel_stats.csv"), os.path.join(OUT, f"{tag}_kernel_stats_{variant}.csv"))
 old = {}
-for prev in ("r03_pmc_hbm.json", "r02_pmc_hbm.json"):  # the correction note and the membench calibration are carried along
+for prev in ("r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json"):  # the correction note and the membench calibration are carried along
     if os.path.exists(os.path.join(OUT, prev)):
         old = json.load(open(os.path.join(OUT, prev)))
         break
@@ -93,7 +93,7 @@ if fw:
     traffic[f"{bench['config']['workload']}/b{frames}/local"] = {"hbm_bytes_per_launch": fw[0]["hbm_bytes_per_launch_corrected"], "source": f"profiles/{tag}_pmc_hbm.json", "kernels_hash": bench_mod.kernels_hash()}
 json.dump(traffic, open(os.path.join(OUT, "hbm_traffic.json"), "w"), indent=1)
 # SQ counters: mean per dispatch and kernel, default path and the table-free variant
-sq_lines = ["rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py [--sat local] --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2  (tools/profile_round.sh, three passes each; cfg2, 128 frames per launch)",
+sq_lines = ["rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py [--sat local] --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2  (tools/profile_round.sh, three passes each; cfg2, " + str(frames) + " frames per launch)",
             "mean counter value per dispatch.  SQ_ACTIVE_INST_VALU is in ~4-cycle units per SIMD: busy fraction = 4 x value / (1024 SIMDs x GRBM_GUI_ACTIVE / 8);",
             "SQ_ACTIVE_INST_LDS in ~2-cycle units per CU: 2 x value / (256 CUs x GRBM_GUI_ACTIVE / 8); SALU: one issue slot per SIMD every 4 cycles.", ""]
 for run in ("sq_default", "sq_local"):
@@ -120,12 +120,12 @@ for run in ("sq_default", "sq_local"):
             sq_lines.append(f"   {c:45s} {sv / n:16.1f}   (x{n})")
 open(os.path.join(OUT, f"{tag}_pmc_sq.txt"), "w").write("\n".join(sq_lines) + "\n")
 sweep = {}
-for b in (1, 8, 32, 64, 128, 256):
+for b in (1, 8, 32, 64, 128, 256, 512):
     d = json.loads(open(os.path.join(P, f"bench_b{b}.json")).read())
     sweep[str(b)] = {"frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "sat_frac_of_8TBs": d["roofline"]["frac"], "stage_ms": d["stage_ms_per_step"]}
 tw = json.loads(open(os.path.join(P, "bench_twopass.json")).read())
 extra = {"batch_sweep": sweep,
-         "twopass_at_128": {"frames_per_s": tw["value"], "sat_launch_ms": tw["roofline"]["launch_ms"], "sat_frac": tw["roofline"]["frac"]},
+         f"twopass_at_{frames}": {"frames_per_s": tw["value"], "sat_launch_ms": tw["roofline"]["launch_ms"], "sat_frac": tw["roofline"]["frac"]},
          "stagebench_cfg5": open(os.path.join(P, "stage_cfg5.txt")).read().strip().splitlines(),
          "stagebench_cfg1": open(os.path.join(P, "stage_cfg1.txt")).read().strip().splitlines(),
          "extras_of_the_bench_line": bench.get("extras")}

@@ -3,13 +3,17 @@
 # rocprofv3: kernel trace + stats in one run, PMC counters in separate passes (never combined with other trace domains); the program
 # after `--` is always python3 itself.
 set -e
+# PART=1 (default, headline: bench line, batch sweep, kernel stats, HBM bytes), PART=2 (variants, SQ counters, other shapes): each fits one gpurun call
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
-rm -rf $O && mkdir -p $O
+PART=${PART:-1}
+[ "$PART" = 1 ] && rm -rf $O
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [ "$PART" = 1 ]; then
 timeout -k 10 400 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 echo "bench default done"
-for b in 1 8 32 64 128 256; do
+for b in 1 8 32 64 128 256 512; do
   timeout -k 10 200 python3 $R/bench.py --batch $b --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/bench_b$b.json
 done
 echo "batch sweep done"
@@ -18,6 +22,8 @@ echo "kernel stats done"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
 echo "pmc done"
+exit 0
+fi
 # the optional variant without a table (k_flat_walk) and the NEAREST reading of resampling.cl:50 (k_resample_staged<0, 2>): kernel stats + HBM bytes
 for v in "local:--sat local" "nearest:--sampler nearest"; do
   tag=${v%%:*}; flags=${v#*:}
