@@ -45,7 +45,10 @@ struct VpImage {
 struct VpTuning {
 	int sat_workgroups_per_cu = 0; // resident workgroups per CU of the single-pass SAT (2..8; 5 and 6 have their own register budget); 0 = 5, and 4 below 64 frames per launch
 	int resample_xcd_bands = -1;   // staged resampling: XCD-contiguous tile bands; -1 = automatic (on for >= 4096 tiles per frame group)
-	int resample_float_stage = 1;  // staged Bayer resampling, BILINEAR_RTZ: box staged as floats (1) or bytes (0)
+#ifndef VP_RS_STAGE_DEFAULT
+#define VP_RS_STAGE_DEFAULT 2
+#endif
+	int resample_float_stage = VP_RS_STAGE_DEFAULT;  // staged Bayer resampling, BILINEAR_RTZ: box staged as aligned float pairs (2, default), floats (1) or bytes (0)
 	int resample_bgr_staged = 1;   // BGR8 sensors: staged kernel (1) or the generic mapped kernel (0)
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)

@@ -249,6 +249,29 @@ __device__ __forceinline__ uint32_t drgb_pack(uint32_t r, uint32_t g, uint32_t b
 	return dr | (dg << 8) | (db << 16) | 0xFF000000u;
 }
 
+// dRGB + RGBA8 packing in 7 instructions instead of 11.  Each channel is (3c + k) >> 2 with k = 510 - (r+g+b), a byte (0 <= 2c - d - e + 510 <= 1020).
+// Scaled by 64 the byte sits in bits 8..15: 64 (3c + k) = 192 c + (32640 - 64 s), one 24-bit multiply-add per channel on a common addend (32-bit
+// wrap-around: the addend may be negative, the sum never is), and two v_perm_b32 gather byte 1 of the three words behind an 0xFF alpha.  Same integers
+// as drgb_pack, no rounding involved.
+__device__ __forceinline__ uint32_t drgb_pack7(uint32_t r, uint32_t g, uint32_t b) {
+	const uint32_t s = r + g + b;
+	const uint32_t k64 = 32640u - (s << 6);
+	const uint32_t x = __umul24(r, 192u) + k64, y = __umul24(g, 192u) + k64, z = __umul24(b, 192u) + k64;
+	const uint32_t xy = __builtin_amdgcn_perm(y, x, 0x0c0c0501u); // [x.b1, y.b1, 0, 0]
+	return __builtin_amdgcn_perm(z, xy, 0x0d050100u);             // [x.b1, y.b1, z.b1, 0xFF]
+}
+typedef float vp_f2 __attribute__((ext_vector_type(2)));
+typedef float vp_f4 __attribute__((ext_vector_type(4)));
+// w00*t00 + w10*t10 + w01*t01 + w11*t11 of ONE channel whose texel pairs arrive as 8-byte LDS reads: (t00, t10) from footprint row 0, (t01, t11) from row
+// 1; w0 = (w00, w10), w1 = (w01, w11).  Two v_pk_mul_f32 + three additions in the order of the sampler definition (sample<>(), bilin()).
+__device__ __forceinline__ float bilin_pairs(vp_f2 w0, vp_f2 w1, vp_f2 row0, vp_f2 row1) {
+	const vp_f2 m0 = w0 * row0, m1 = w1 * row1;
+	float t = m0.x + m0.y;
+	t = t + m1.x;
+	t = t + m1.y;
+	return t;
+}
+
 // Staged variant of the Bayer footprint: all texels of one sensor row that a flat pixel needs (two even-column and two
 // odd-column bytes) lie within 5 consecutive bytes starting at an even column, hence inside TWO aligned dwords.  One
 // v_perm_b32 per row gathers them, v_cvt_f32_ubyte0..3 converts them.
@@ -391,12 +414,14 @@ __device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
 
 // Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
 // sample directly (bayer4_eval); results are identical either way.
-// VARIANT 0: BILINEAR_RTZ, box staged as bytes; 1: BILINEAR_RTZ, box staged as floats (default); 2: NEAREST, box staged as bytes.
+// VARIANT 0: BILINEAR_RTZ, box staged as bytes; 1: BILINEAR_RTZ, box staged as floats; 2: NEAREST, box staged as bytes; 3 (default): BILINEAR_RTZ, box staged as
+// aligned float PAIRS (run_pair) where the workgroup's footprints allow it, as bytes elsewhere (the tiles on the left / right image border).
 template<int LAYOUT, int VARIANT, bool NTS>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch, int xcd_map) {
-	__shared__ uint32_t stage[RESAMPLE_FPT][STAGE_DW];
-	__shared__ uint32_t red[4][2];
+	__shared__ __attribute__((aligned(16))) uint32_t stage[RESAMPLE_FPT][STAGE_DW];
+	__shared__ __attribute__((aligned(16))) uint32_t pair_rows[2][4][64]; // run_pair: the workgroup's 4 x 64 flat pixels of one frame (the strip record is gathered from them), double buffered
+	__shared__ uint32_t red[4][3];
 	const unsigned bz = blockIdx.z;
 	// Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  A workgroup's box shares its 64/128-byte lines with the
 	// boxes left and right of it and two to four sensor rows with those above and below; with the plain mapping horizontal
@@ -417,7 +442,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 	const size_t npx = (size_t)fw * fh;
 	const uint32_t rowb = 2u * (uint32_t)qw;
 	{
-		constexpr bool FLT = VARIANT == 1, NEAR = VARIANT == 2;
+		constexpr bool FLT = VARIANT == 1, NEAR = VARIANT == 2, PAIR = VARIANT == 3;
 		Bayer4Stage g = {};
 		// NEAREST (spec 8.2: texel = floor(u), clamp-to-edge): one texel per positional channel -- even row e / odd row o of the
 		// sensor, even byte column ca / odd byte column cb (resampling.cl:64-79 with the +-0.25 offsets)
@@ -433,13 +458,17 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 		const uint32_t lo_w = wave_reduce_pk16<false>(NEAR ? (uint32_t)(min(nca, ncb) >> 2) | ((uint32_t)min(ne, no) << 16) : (uint32_t)g.d0 | ((uint32_t)min(g.re0, g.ro0) << 16));
 		const uint32_t hi_w = wave_reduce_pk16<true>(NEAR ? (uint32_t)((max(nca, ncb) >> 2) + 1) | ((uint32_t)max(ne, no) << 16) : (uint32_t)(g.d0 + 2) | ((uint32_t)max(g.re1, g.ro1) << 16));
 		const int tid = threadIdx.y * 64 + threadIdx.x;
+		// (run_pair) does any pixel of the workgroup have a footprint whose second column is NOT the first one's right neighbour (clamp-to-edge at the image border)?
+		const bool xclamp_w = PAIR && __any(g.ia1 != g.ia0 + 1 || g.ib1 != g.ib0 + 1);
 		if(threadIdx.x == 0) {
 			red[threadIdx.y][0] = lo_w;
 			red[threadIdx.y][1] = hi_w;
+			red[threadIdx.y][2] = xclamp_w;
 		}
 		__syncthreads();
 		const uint32_t lo = pk16_min(pk16_min(red[0][0], red[1][0]), pk16_min(red[2][0], red[3][0]));
 		const uint32_t hi = pk16_max(pk16_max(red[0][1], red[1][1]), pk16_max(red[2][1], red[3][1]));
+		const bool xclamp = (red[0][2] | red[1][2] | red[2][2] | red[3][2]) != 0;
 		const int cmin = (int)(lo & 0xFFFF), rmin = (int)(lo >> 16), cmax = (int)(hi & 0xFFFF), rmax = (int)(hi >> 16);
 		const int wdw = cmax - cmin, hr = rmax - rmin + 1, ndw = wdw * hr;
 		const size_t raw_span = (size_t)(f1 - f0) * src_frame_bytes, flat_span = (size_t)(f1 - f0) * npx * 4;
@@ -566,6 +595,94 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				}
 				flush(nf - 1);
 			};
+			// PAIR-STAGED form of run_flt (the default where its conditions hold).  The float-staged kernel is bound by LDS cycles, not by the VALU (taking a
+			// quarter of its VALU instructions out, or adding LDS stores, moves it the other way round: profiles/r05_resample_lds_bound.json): 16 ds_read_b32
+			// per pixel and frame at 2 cycles per wave instruction.  A ds_read_b64 costs the same 2 cycles (MI355X_MICROARCH.md, LDS), and the two texels of a
+			// footprint row are neighbours -- but a pair starts at an odd or an even cell, and an 8-byte LDS access off its alignment is replayed at 64 cycles.  So
+			// the box is staged as PAIRS: plane P of a box row holds (T[k], T[k+1]) for every cell k, each texel twice, every pair 8-byte aligned: 8 reads per
+			// pixel and frame instead of 16.  The staging thread of box dword d owns cells 2d, 2d+1 of both planes and needs cell 2d+2 for its second pair: the
+			// sensor dword of its right-hand neighbour, one DPP wave shift away -- which is why a wavefront here stages WHOLE box rows (floor(64 / wdw) of them).
+			// Conditions (workgroup-uniform; otherwise run_flt, same results): no footprint of the workgroup is clamped in x (its second column is the first one's
+			// neighbour: all but the tiles on the left / right image border), and four wavefronts' worth of whole rows cover the box.
+			auto run_pair = [&]() {
+				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: 2 wdw pairs | plane B: 2 wdw pairs]
+				const int RP = 8 * wdw;                             // floats per box row
+				const int rpw = 64 / wdw;                           // whole box rows per wavefront (the caller checked wdw <= 64)
+				const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+				const int rl = (int)(((float)threadIdx.x + 0.5f) * inv_wdw), ocol = (int)threadIdx.x - rl * wdw, orow = wave * rpw + rl;
+				const bool stager = rl < rpw && orow < hr;
+				const uint32_t goff = stager ? (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol) : (uint32_t)rmin * rowb + 4u * (uint32_t)cmin;
+				float* wa = F + (stager ? orow * RP + 4 * ocol : 0);
+				uint32_t pre[RESAMPLE_FPT];
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff, (uint32_t)min(j, nf - 1) * fb_raw, 0);
+				const bool any_stager = wave * rpw < hr; // wavefront-uniform: this wavefront stages at least one row
+				auto put = [&](int buf, uint32_t v) {
+					if(any_stager) {
+						const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); // wave_shl:1 -- the dword of lane + 1 (all lanes take part)
+						if(stager) {
+							const float a0 = (float)(v & 0xFF), b0 = (float)((v >> 8) & 0xFF), a1 = (float)((v >> 16) & 0xFF), b1 = (float)(v >> 24);
+							const float a2 = (float)(nb & 0xFF), b2 = (float)((nb >> 8) & 0xFF);
+							*reinterpret_cast<vp_f4*>(wa + buf * 2048) = vp_f4{a0, a1, a1, a2};
+							*reinterpret_cast<vp_f4*>(wa + buf * 2048 + 4 * wdw) = vp_f4{b0, b1, b1, b2};
+						}
+					}
+				};
+				// float indices of the 8 texel pairs (frame independent): pair of cell i sits at 2 (i - 2 cmin) in plane A, + 4 wdw in plane B
+				const int pa = 2 * (g.ia0 - 2 * cmin), pb = 2 * (g.ib0 - 2 * cmin) + 4 * wdw;
+				const int r0 = (g.re0 - rmin) * RP, r1 = (g.re1 - rmin) * RP, r2 = (g.ro0 - rmin) * RP, r3 = (g.ro1 - rmin) * RP;
+				const vp_f2* q00 = reinterpret_cast<const vp_f2*>(F + r0 + pa); const vp_f2* q01 = reinterpret_cast<const vp_f2*>(F + r1 + pa);
+				const vp_f2* q10 = reinterpret_cast<const vp_f2*>(F + r0 + pb); const vp_f2* q11 = reinterpret_cast<const vp_f2*>(F + r1 + pb);
+				const vp_f2* q20 = reinterpret_cast<const vp_f2*>(F + r2 + pa); const vp_f2* q21 = reinterpret_cast<const vp_f2*>(F + r3 + pa);
+				const vp_f2* q30 = reinterpret_cast<const vp_f2*>(F + r2 + pb); const vp_f2* q31 = reinterpret_cast<const vp_f2*>(F + r3 + pb);
+				// weights as (w00, w10), (w01, w11) per channel.  The two greens are halved after the conversion (resampling.cl:66,76): scaling a weight by 0.5
+				// scales every product and partial sum EXACTLY (a weight is 0 or >= 8e-16: nothing underflows), so the sum comes out as t / 2, and
+				// (uint)(t / 2) = (uint)t / 2 for t >= 0 -- the halving for free.
+				const float oxa = 1.0f - g.xa, oxb = 1.0f - g.xb, oya = 1.0f - g.ya, oyb = 1.0f - g.yb;
+				const float h0 = LAYOUT == VP_LAYOUT_RGGB ? 1.0f : 0.5f, h1 = LAYOUT == VP_LAYOUT_RGGB ? 0.5f : 1.0f, h2 = h1, h3 = h0;
+				const vp_f2 w0a = vp_f2{(oxa * oya) * h0, (g.xa * oya) * h0}, w0b = vp_f2{(oxa * g.ya) * h0, (g.xa * g.ya) * h0};
+				const vp_f2 w1a = vp_f2{(oxb * oya) * h1, (g.xb * oya) * h1}, w1b = vp_f2{(oxb * g.ya) * h1, (g.xb * g.ya) * h1};
+				const vp_f2 w2a = vp_f2{(oxa * oyb) * h2, (g.xa * oyb) * h2}, w2b = vp_f2{(oxa * g.yb) * h2, (g.xa * g.yb) * h2};
+				const vp_f2 w3a = vp_f2{(oxb * oyb) * h3, (g.xb * oyb) * h3}, w3b = vp_f2{(oxb * g.yb) * h3, (g.xb * g.yb) * h3};
+				// halo strips: as run_flt (one wavefront stores the previous frame's record as a whole)
+				const bool agg = strips.base != nullptr;
+				const uint32_t voff_rec = 4u * (((uint32_t)bxi * shp + (uint32_t)byi * 4u) * 2u * so + (uint32_t)threadIdx.x);
+				const bool rec_lane = threadIdx.x < 8 * strips.o;
+				// every wavefront parks its 64 pixels with ds_write_addtid_b32 (address = M0 + 4 lane: no address VGPR to ship, 2 LDS cycles per wave instruction
+				// instead of the 4 of ds_write_b32); the flushing wavefront picks the record's pixels out of the four rows: lane t = row t / 2o, element t % 2o
+				const uint32_t row_m0[2] = {(uint32_t)(uintptr_t)&pair_rows[0][wave][0], (uint32_t)(uintptr_t)&pair_rows[1][wave][0]};
+				const int rec_row = (int)threadIdx.x / (2 * (int)so), rec_e = (int)threadIdx.x - rec_row * 2 * (int)so;
+				const uint32_t* rec_src = &pair_rows[0][rec_lane ? rec_row : 0][rec_lane ? (rec_e < (int)so ? rec_e : 64 - 2 * (int)so + rec_e) : 0];
+				auto park_row = [&](int j, uint32_t px4) {
+					// (an asm statement's LDS store is not counted by the compiler: the s_waitcnt before the frame's barrier below covers it; nor are its hazards
+					// padded: an SALU write of M0 needs one wait state before an LDS add-TID instruction)
+					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(px4), "s"(__builtin_amdgcn_readfirstlane((int)row_m0[j & 1])) : "m0", "memory");
+				};
+				auto flush = [&](int j) {
+					if(agg && wave == (j & 3) && rec_lane)
+						__builtin_amdgcn_raw_buffer_store_b32(rec_src[(j & 1) * 256], rs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
+				};
+				put(0, pre[0]);
+				__syncthreads();
+#pragma unroll
+				for(int j = 0; j < RESAMPLE_FPT; j++) {
+					if(j >= nf) break;
+					const int o = (j & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
+					const float t0 = bilin_pairs(w0a, w0b, q00[o], q01[o]);
+					const float t1 = bilin_pairs(w1a, w1b, q10[o], q11[o]);
+					const float t2 = bilin_pairs(w2a, w2b, q20[o], q21[o]);
+					const float t3 = bilin_pairs(w3a, w3b, q30[o], q31[o]);
+					const uint32_t p0 = (uint32_t)t0, p1 = (uint32_t)t1, p2 = (uint32_t)t2, p3 = (uint32_t)t3; // the two greens come out halved
+					if(j + 1 < nf) put((j + 1) & 1, pre[j + 1 < RESAMPLE_FPT ? j + 1 : j]);
+					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(p0, p1 + p2, p3) : drgb_pack7(p1, p0 + p3, p2);
+					store_flat(px4, (uint32_t)j * fb_flat);
+					if(agg) park_row(j, px4);
+					if(j > 0) flush(j - 1);
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					__syncthreads();
+				}
+				flush(nf - 1);
+			};
 			// NEAREST: the boxes of all frames up front (as `run`), then four byte picks per pixel and frame
 			auto run_near = [&]() {
 				const int own = tid < ndw ? tid : 0, orow = (int)(((float)own + 0.5f) * inv_wdw), ocol = own - orow * wdw;
@@ -589,7 +706,10 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
 				}
 			};
+			// (two float-staged bodies in one instantiation cost 86 VGPRs instead of 68 -- five wavefronts per SIMD instead of seven: VARIANT 3 falls back to bytes)
+			const bool pair_ok = PAIR && !xclamp && wdw > 0 && wdw <= 64 && 4 * (64 / wdw) >= hr; // (8 ndw floats per buffer <= 2048: ndw <= STAGE_DW holds already)
 			if(NEAR) run_near();
+			else if(PAIR && pair_ok) run_pair();
 			else if(FLT) run_flt();
 			else if(ndw <= 256) run(std::integral_constant<int, 1>());
 			else run(std::integral_constant<int, STAGE_DW / 256>());
@@ -853,8 +973,8 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	if(layout != VP_LAYOUT_BGR && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
 			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
 		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
-		const bool flt = ctx->tune.resample_float_stage != 0; // float-staged variant (default; vp_ctx_tune "resample_float_stage" 0 selects the byte-staged one)
-		const int variant = sampler_mode == VP_SAMPLER_NEAREST ? 2 : (flt ? 1 : 0);
+		const int fs = ctx->tune.resample_float_stage; // 2 (default): aligned float pairs; 1: floats; 0: bytes (vp_ctx_tune "resample_float_stage")
+		const int variant = sampler_mode == VP_SAMPLER_NEAREST ? 2 : (fs >= 2 ? 3 : fs == 1 ? 1 : 0);
 		// XCD-contiguous tile bands for large frames (measured at 2048x1536: HBM reads 1.38 -> 0.60 GB per 128 frames, time unchanged;
 		// at 640x480 the bands unbalance the XCDs: 87 -> 99 us, so small grids keep the plain mapping).  vp_ctx_tune "resample_xcd_bands" forces it.
 		const int xcd_map = ctx->tune.resample_xcd_bands >= 0 ? ctx->tune.resample_xcd_bands : (grid.x * grid.y >= 4096u);
@@ -865,11 +985,13 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 			else k_resample_staged<L, V, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map); \
 		} while(0)
 		if(layout == VP_LAYOUT_RGGB) {
-			if(variant == 2) VP_RST(VP_LAYOUT_RGGB, 2);
+			if(variant == 3) VP_RST(VP_LAYOUT_RGGB, 3);
+			else if(variant == 2) VP_RST(VP_LAYOUT_RGGB, 2);
 			else if(variant == 1) VP_RST(VP_LAYOUT_RGGB, 1);
 			else VP_RST(VP_LAYOUT_RGGB, 0);
 		} else {
-			if(variant == 2) VP_RST(VP_LAYOUT_GRBG, 2);
+			if(variant == 3) VP_RST(VP_LAYOUT_GRBG, 3);
+			else if(variant == 2) VP_RST(VP_LAYOUT_GRBG, 2);
 			else if(variant == 1) VP_RST(VP_LAYOUT_GRBG, 1);
 			else VP_RST(VP_LAYOUT_GRBG, 0);
 		}
