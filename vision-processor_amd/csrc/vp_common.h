@@ -48,7 +48,7 @@ struct VpTuning {
 #ifndef VP_RS_STAGE_DEFAULT
 #define VP_RS_STAGE_DEFAULT 2
 #endif
-	int resample_float_stage = VP_RS_STAGE_DEFAULT;  // staged Bayer resampling, BILINEAR_RTZ: box staged as aligned float pairs (2, default), floats (1) or bytes (0)
+	int resample_float_stage = VP_RS_STAGE_DEFAULT;  // staged Bayer resampling, BILINEAR_RTZ: box staged as floats of two frames side by side (2, default), floats (1) or bytes (0)
 	int resample_bgr_staged = 1;   // BGR8 sensors: staged kernel (1) or the generic mapped kernel (0)
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)

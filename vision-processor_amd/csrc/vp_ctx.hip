@@ -113,7 +113,7 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 		VP_REQUIRE(value >= -1 && value <= 1, "vp_ctx_tune: resample_xcd_bands takes -1 (automatic), 0 or 1");
 		ctx->tune.resample_xcd_bands = value;
 	} else if(k == "resample_float_stage") {
-		VP_REQUIRE(value >= 0 && value <= 2, "vp_ctx_tune: resample_float_stage %d: 0 (bytes), 1 (floats) or 2 (aligned float pairs)", value);
+		VP_REQUIRE(value >= 0 && value <= 2, "vp_ctx_tune: resample_float_stage %d: 0 (bytes), 1 (floats) or 2 (floats, two frames side by side)", value);
 		ctx->tune.resample_float_stage = value;
 	} else if(k == "resample_bgr_staged") {
 		ctx->tune.resample_bgr_staged = value != 0;

@@ -262,15 +262,6 @@ __device__ __forceinline__ uint32_t drgb_pack7(uint32_t r, uint32_t g, uint32_t 
 }
 typedef float vp_f2 __attribute__((ext_vector_type(2)));
 typedef float vp_f4 __attribute__((ext_vector_type(4)));
-// w00*t00 + w10*t10 + w01*t01 + w11*t11 of ONE channel whose texel pairs arrive as 8-byte LDS reads: (t00, t10) from footprint row 0, (t01, t11) from row
-// 1; w0 = (w00, w10), w1 = (w01, w11).  Two v_pk_mul_f32 + three additions in the order of the sampler definition (sample<>(), bilin()).
-__device__ __forceinline__ float bilin_pairs(vp_f2 w0, vp_f2 w1, vp_f2 row0, vp_f2 row1) {
-	const vp_f2 m0 = w0 * row0, m1 = w1 * row1;
-	float t = m0.x + m0.y;
-	t = t + m1.x;
-	t = t + m1.y;
-	return t;
-}
 
 // Staged variant of the Bayer footprint: all texels of one sensor row that a flat pixel needs (two even-column and two
 // odd-column bytes) lie within 5 consecutive bytes starting at an even column, hence inside TWO aligned dwords.  One
@@ -415,12 +406,12 @@ __device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
 // Bayer + BILINEAR_RTZ, sensor rows dword aligned (host-checked): the staged kernel.  Workgroups whose box exceeds the stage
 // sample directly (bayer4_eval); results are identical either way.
 // VARIANT 0: BILINEAR_RTZ, box staged as bytes; 1: BILINEAR_RTZ, box staged as floats; 2: NEAREST, box staged as bytes; 3 (default): BILINEAR_RTZ, box staged as
-// aligned float PAIRS (run_pair) where the workgroup's footprints allow it, as bytes elsewhere (the tiles on the left / right image border).
+// floats of two frames side by side (run_fp) where the workgroup's footprints allow it, as bytes elsewhere (the tiles on the left / right image border).
 template<int LAYOUT, int VARIANT, bool NTS>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch, int xcd_map) {
 	__shared__ __attribute__((aligned(16))) uint32_t stage[RESAMPLE_FPT][STAGE_DW];
-	__shared__ __attribute__((aligned(16))) uint32_t pair_rows[2][4][64]; // run_pair: the workgroup's 4 x 64 flat pixels of one frame (the strip record is gathered from them), double buffered
+	__shared__ __attribute__((aligned(16))) uint32_t fp_rows[2][2][4][64]; // run_fp: the workgroup's 4 x 64 flat pixels of the two frames of a step (the strip records are gathered from them), double buffered
 	__shared__ uint32_t red[4][3];
 	const unsigned bz = blockIdx.z;
 	// Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  A workgroup's box shares its 64/128-byte lines with the
@@ -442,7 +433,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 	const size_t npx = (size_t)fw * fh;
 	const uint32_t rowb = 2u * (uint32_t)qw;
 	{
-		constexpr bool FLT = VARIANT == 1, NEAR = VARIANT == 2, PAIR = VARIANT == 3;
+		constexpr bool FLT = VARIANT == 1, NEAR = VARIANT == 2, FP = VARIANT == 3;
 		Bayer4Stage g = {};
 		// NEAREST (spec 8.2: texel = floor(u), clamp-to-edge): one texel per positional channel -- even row e / odd row o of the
 		// sensor, even byte column ca / odd byte column cb (resampling.cl:64-79 with the +-0.25 offsets)
@@ -458,8 +449,8 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 		const uint32_t lo_w = wave_reduce_pk16<false>(NEAR ? (uint32_t)(min(nca, ncb) >> 2) | ((uint32_t)min(ne, no) << 16) : (uint32_t)g.d0 | ((uint32_t)min(g.re0, g.ro0) << 16));
 		const uint32_t hi_w = wave_reduce_pk16<true>(NEAR ? (uint32_t)((max(nca, ncb) >> 2) + 1) | ((uint32_t)max(ne, no) << 16) : (uint32_t)(g.d0 + 2) | ((uint32_t)max(g.re1, g.ro1) << 16));
 		const int tid = threadIdx.y * 64 + threadIdx.x;
-		// (run_pair) does any pixel of the workgroup have a footprint whose second column is NOT the first one's right neighbour (clamp-to-edge at the image border)?
-		const bool xclamp_w = PAIR && __any(g.ia1 != g.ia0 + 1 || g.ib1 != g.ib0 + 1);
+		// (run_fp) does any pixel of the workgroup have a footprint whose second column is NOT the first one's right neighbour (clamp-to-edge at the image border)?
+		const bool xclamp_w = FP && __any(g.ia1 != g.ia0 + 1 || g.ib1 != g.ib0 + 1);
 		if(threadIdx.x == 0) {
 			red[threadIdx.y][0] = lo_w;
 			red[threadIdx.y][1] = hi_w;
@@ -595,93 +586,118 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				}
 				flush(nf - 1);
 			};
-			// PAIR-STAGED form of run_flt (the default where its conditions hold).  The float-staged kernel is bound by LDS cycles, not by the VALU (taking a
-			// quarter of its VALU instructions out, or adding LDS stores, moves it the other way round: profiles/r05_resample_lds_bound.json): 16 ds_read_b32
-			// per pixel and frame at 2 cycles per wave instruction.  A ds_read_b64 costs the same 2 cycles (MI355X_MICROARCH.md, LDS), and the two texels of a
-			// footprint row are neighbours -- but a pair starts at an odd or an even cell, and an 8-byte LDS access off its alignment is replayed at 64 cycles.  So
-			// the box is staged as PAIRS: plane P of a box row holds (T[k], T[k+1]) for every cell k, each texel twice, every pair 8-byte aligned: 8 reads per
-			// pixel and frame instead of 16.  The staging thread of box dword d owns cells 2d, 2d+1 of both planes and needs cell 2d+2 for its second pair: the
-			// sensor dword of its right-hand neighbour, one DPP wave shift away -- which is why a wavefront here stages WHOLE box rows (floor(64 / wdw) of them).
-			// Conditions (workgroup-uniform; otherwise run_flt, same results): no footprint of the workgroup is clamped in x (its second column is the first one's
-			// neighbour: all but the tiles on the left / right image border), and four wavefronts' worth of whole rows cover the box.
-			auto run_pair = [&]() {
-				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: 2 wdw pairs | plane B: 2 wdw pairs]
+			// FRAME-PAIR form of run_flt (VARIANT 3, the default).  The float-staged kernel is bound by LDS cycles, not by the VALU (taking a quarter of its VALU
+			// instructions out changes nothing, adding LDS stores slows it down: profiles/r05_resample_lds_bound.json): 16 ds_read_b32 per pixel and frame at 2
+			// cycles per wave instruction -- and a ds_read_b64 costs the same 2 cycles (MI355X_MICROARCH.md, LDS).  So the LDS image holds, for every cell of the
+			// box, the texel of TWO consecutive frames side by side (8 bytes, always aligned: an 8-byte access off its alignment is replayed at 64 cycles), and a
+			// pixel computes both frames at once: the weights are the same, so every product and every partial sum is one packed instruction for the two frames
+			// (v_pk_mul_f32 taking one half of a weight pair for both lanes, v_pk_add_f32), in the order of the sampler definition.  Per pixel and frame: 8 LDS
+			// reads instead of 16, 14 instead of 17 instructions for the four sums, half a barrier; per staged dword one ds_write_b128 per plane and frame PAIR.
+			// [First built with CELL pairs (T[k], T[k+1]) per frame: every texel stored twice, the neighbour's dword fetched by a DPP wave shift, whole box rows per
+			// staging wavefront; 1 % slower than this and more conditions.]  Condition (workgroup-uniform; otherwise the byte stage, same results): no footprint of
+			// the workgroup is clamped in x -- the second column's texel is read at + 8 bytes from the first one's address register -- which holds for all tiles
+			// but those on the left / right image border.
+			auto run_fp = [&]() {
+				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: 2 wdw cells x (frame f, frame f + 1) | plane B likewise]
 				const int RP = 8 * wdw;                             // floats per box row
-				const int rpw = 64 / wdw;                           // whole box rows per wavefront (the caller checked wdw <= 64)
 				const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
-				const int rl = (int)(((float)threadIdx.x + 0.5f) * inv_wdw), ocol = (int)threadIdx.x - rl * wdw, orow = wave * rpw + rl;
-				const bool stager = rl < rpw && orow < hr;
-				const uint32_t goff = stager ? (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol) : (uint32_t)rmin * rowb + 4u * (uint32_t)cmin;
-				float* wa = F + (stager ? orow * RP + 4 * ocol : 0);
+				const int own = tid < ndw ? tid : 0, orow = (int)(((float)own + 0.5f) * inv_wdw), ocol = own - orow * wdw;
+				const uint32_t goff = (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol);
+				float* wa = F + orow * RP + 4 * ocol; // cells 2 ocol, 2 ocol + 1 of plane A; plane B 4 wdw floats on
 				uint32_t pre[RESAMPLE_FPT];
 #pragma unroll
 				for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff, (uint32_t)min(j, nf - 1) * fb_raw, 0);
-				const bool any_stager = wave * rpw < hr; // wavefront-uniform: this wavefront stages at least one row
-				auto put = [&](int buf, uint32_t v) {
-					if(any_stager) {
-						const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); // wave_shl:1 -- the dword of lane + 1 (all lanes take part)
-						if(stager) {
-							const float a0 = (float)(v & 0xFF), b0 = (float)((v >> 8) & 0xFF), a1 = (float)((v >> 16) & 0xFF), b1 = (float)(v >> 24);
-							const float a2 = (float)(nb & 0xFF), b2 = (float)((nb >> 8) & 0xFF);
-							*reinterpret_cast<vp_f4*>(wa + buf * 2048) = vp_f4{a0, a1, a1, a2};
-							*reinterpret_cast<vp_f4*>(wa + buf * 2048 + 4 * wdw) = vp_f4{b0, b1, b1, b2};
-						}
+				auto put = [&](int buf, uint32_t v0, uint32_t v1) { // frames f (v0) and f + 1 (v1) of this thread's dword
+					if(tid < ndw) {
+						*reinterpret_cast<vp_f4*>(wa + buf * 2048) = vp_f4{(float)(v0 & 0xFF), (float)(v1 & 0xFF), (float)((v0 >> 16) & 0xFF), (float)((v1 >> 16) & 0xFF)};
+						*reinterpret_cast<vp_f4*>(wa + buf * 2048 + 4 * wdw) = vp_f4{(float)((v0 >> 8) & 0xFF), (float)((v1 >> 8) & 0xFF), (float)(v0 >> 24), (float)(v1 >> 24)};
 					}
 				};
-				// float indices of the 8 texel pairs (frame independent): pair of cell i sits at 2 (i - 2 cmin) in plane A, + 4 wdw in plane B
+				// cell i of plane A sits at float 2 (i - 2 cmin) of its box row, plane B 4 wdw floats on; the footprint's second column is the next cell ([1])
 				const int pa = 2 * (g.ia0 - 2 * cmin), pb = 2 * (g.ib0 - 2 * cmin) + 4 * wdw;
 				const int r0 = (g.re0 - rmin) * RP, r1 = (g.re1 - rmin) * RP, r2 = (g.ro0 - rmin) * RP, r3 = (g.ro1 - rmin) * RP;
 				const vp_f2* q00 = reinterpret_cast<const vp_f2*>(F + r0 + pa); const vp_f2* q01 = reinterpret_cast<const vp_f2*>(F + r1 + pa);
 				const vp_f2* q10 = reinterpret_cast<const vp_f2*>(F + r0 + pb); const vp_f2* q11 = reinterpret_cast<const vp_f2*>(F + r1 + pb);
 				const vp_f2* q20 = reinterpret_cast<const vp_f2*>(F + r2 + pa); const vp_f2* q21 = reinterpret_cast<const vp_f2*>(F + r3 + pa);
 				const vp_f2* q30 = reinterpret_cast<const vp_f2*>(F + r2 + pb); const vp_f2* q31 = reinterpret_cast<const vp_f2*>(F + r3 + pb);
-				// weights as (w00, w10), (w01, w11) per channel.  The two greens are halved after the conversion (resampling.cl:66,76): scaling a weight by 0.5
-				// scales every product and partial sum EXACTLY (a weight is 0 or >= 8e-16: nothing underflows), so the sum comes out as t / 2, and
-				// (uint)(t / 2) = (uint)t / 2 for t >= 0 -- the halving for free.
+				// the 16 weights; the two greens' carry a factor 0.5, so their sums come out halved as resampling.cl:66,76 halves them: scaling a weight by 0.5 scales every
+				// product and partial sum EXACTLY (a weight is 0 or >= 8e-16: nothing underflows), and (uint)(t / 2) = (uint)t / 2 for t >= 0
 				const float oxa = 1.0f - g.xa, oxb = 1.0f - g.xb, oya = 1.0f - g.ya, oyb = 1.0f - g.yb;
 				const float h0 = LAYOUT == VP_LAYOUT_RGGB ? 1.0f : 0.5f, h1 = LAYOUT == VP_LAYOUT_RGGB ? 0.5f : 1.0f, h2 = h1, h3 = h0;
+				// kept as register PAIRS (w00, w10), (w01, w11) per channel: a packed multiply takes one half of a pair for both of its lanes (op_sel), so the 16
+				// weights cost 16 registers, not 32 broadcast copies
 				const vp_f2 w0a = vp_f2{(oxa * oya) * h0, (g.xa * oya) * h0}, w0b = vp_f2{(oxa * g.ya) * h0, (g.xa * g.ya) * h0};
 				const vp_f2 w1a = vp_f2{(oxb * oya) * h1, (g.xb * oya) * h1}, w1b = vp_f2{(oxb * g.ya) * h1, (g.xb * g.ya) * h1};
 				const vp_f2 w2a = vp_f2{(oxa * oyb) * h2, (g.xa * oyb) * h2}, w2b = vp_f2{(oxa * g.yb) * h2, (g.xa * g.yb) * h2};
 				const vp_f2 w3a = vp_f2{(oxb * oyb) * h3, (g.xb * oyb) * h3}, w3b = vp_f2{(oxb * g.yb) * h3, (g.xb * g.yb) * h3};
-				// halo strips: as run_flt (one wavefront stores the previous frame's record as a whole)
+				// (volatile: two 8-byte reads 8 bytes apart must NOT be merged into one ds_read2_b64 -- that costs 8 LDS cycles against 2 + 2, MI355X_MICROARCH.md, LDS)
+				auto sum2 = [&](vp_f2 wa, vp_f2 wb, const vp_f2* row0, const vp_f2* row1, int o) { // both frames: w00 t00 + w10 t10 + w01 t01 + w11 t11, in that order
+					typedef __attribute__((address_space(3))) const volatile vp_f2 lds_f2;
+					lds_f2* v0 = (lds_f2*)(row0 + o);
+					lds_f2* v1 = (lds_f2*)(row1 + o);
+					const vp_f2 t00 = v0[0], t10 = v0[1], t01 = v1[0], t11 = v1[1];
+					// one half of a weight pair times both frames' texels.  Written as asm because the compiler, given a broadcast, keeps 16 (w, w) register pairs alive
+					// instead of selecting the half in the instruction (op_sel / op_sel_hi: [weight half for lane 0, texel lo], [weight half for lane 1, texel hi])
+					vp_f2 m00, m10, m01, m11;
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m00) : "v"(wa), "v"(t00));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m10) : "v"(wa), "v"(t10));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m01) : "v"(wb), "v"(t01));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m11) : "v"(wb), "v"(t11));
+					vp_f2 t = m00 + m10;
+					t = t + m01;
+					t = t + m11;
+					return t;
+				};
+				// halo strips: every wavefront parks its 64 pixels of both frames (ds_write_addtid_b32), one wavefront per frame stores that frame's record a step later
 				const bool agg = strips.base != nullptr;
 				const uint32_t voff_rec = 4u * (((uint32_t)bxi * shp + (uint32_t)byi * 4u) * 2u * so + (uint32_t)threadIdx.x);
 				const bool rec_lane = threadIdx.x < 8 * strips.o;
-				// every wavefront parks its 64 pixels with ds_write_addtid_b32 (address = M0 + 4 lane: no address VGPR to ship, 2 LDS cycles per wave instruction
-				// instead of the 4 of ds_write_b32); the flushing wavefront picks the record's pixels out of the four rows: lane t = row t / 2o, element t % 2o
-				const uint32_t row_m0[2] = {(uint32_t)(uintptr_t)&pair_rows[0][wave][0], (uint32_t)(uintptr_t)&pair_rows[1][wave][0]};
 				const int rec_row = (int)threadIdx.x / (2 * (int)so), rec_e = (int)threadIdx.x - rec_row * 2 * (int)so;
-				const uint32_t* rec_src = &pair_rows[0][rec_lane ? rec_row : 0][rec_lane ? (rec_e < (int)so ? rec_e : 64 - 2 * (int)so + rec_e) : 0];
-				auto park_row = [&](int j, uint32_t px4) {
-					// (an asm statement's LDS store is not counted by the compiler: the s_waitcnt before the frame's barrier below covers it; nor are its hazards
-					// padded: an SALU write of M0 needs one wait state before an LDS add-TID instruction)
-					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(px4), "s"(__builtin_amdgcn_readfirstlane((int)row_m0[j & 1])) : "m0", "memory");
+				const uint32_t* rec_src = &fp_rows[0][0][rec_lane ? rec_row : 0][rec_lane ? (rec_e < (int)so ? rec_e : 64 - 2 * (int)so + rec_e) : 0];
+				const uint32_t row_m0 = (uint32_t)(uintptr_t)&fp_rows[0][0][wave][0];
+				auto park_row = [&](int j, uint32_t px4) { // frame j: buffer (j >> 1) & 1, half j & 1 (asm: hipcc neither counts the LDS store -- the s_waitcnt before the step's barrier covers it -- nor pads the hazard: an SALU write of M0 needs one wait state before an LDS add-TID instruction)
+					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(px4), "s"(__builtin_amdgcn_readfirstlane((int)(row_m0 + (uint32_t)(((j >> 1) & 1) * 2 + (j & 1)) * 1024u))) : "m0", "memory");
 				};
 				auto flush = [&](int j) {
 					if(agg && wave == (j & 3) && rec_lane)
-						__builtin_amdgcn_raw_buffer_store_b32(rec_src[(j & 1) * 256], rs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
+						__builtin_amdgcn_raw_buffer_store_b32(rec_src[(((j >> 1) & 1) * 2 + (j & 1)) * 256], rs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
 				};
-				put(0, pre[0]);
+				put(0, pre[0], pre[1]);
 				__syncthreads();
 #pragma unroll
-				for(int j = 0; j < RESAMPLE_FPT; j++) {
+				for(int jj = 0; jj < RESAMPLE_FPT / 2; jj++) {
+					const int j = 2 * jj;
 					if(j >= nf) break;
-					const int o = (j & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
-					const float t0 = bilin_pairs(w0a, w0b, q00[o], q01[o]);
-					const float t1 = bilin_pairs(w1a, w1b, q10[o], q11[o]);
-					const float t2 = bilin_pairs(w2a, w2b, q20[o], q21[o]);
-					const float t3 = bilin_pairs(w3a, w3b, q30[o], q31[o]);
-					const uint32_t p0 = (uint32_t)t0, p1 = (uint32_t)t1, p2 = (uint32_t)t2, p3 = (uint32_t)t3; // the two greens come out halved
-					if(j + 1 < nf) put((j + 1) & 1, pre[j + 1 < RESAMPLE_FPT ? j + 1 : j]);
-					const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(p0, p1 + p2, p3) : drgb_pack7(p1, p0 + p3, p2);
-					store_flat(px4, (uint32_t)j * fb_flat);
-					if(agg) park_row(j, px4);
-					if(j > 0) flush(j - 1);
+					const int o = (jj & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
+					// (two channels' texels in flight at a time: all sixteen 8-byte reads up front cost 24 more VGPRs -- five wavefronts per SIMD instead of seven)
+					const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
+					const vp_f2 t1 = sum2(w1a, w1b, q10, q11, o);
+					const uint32_t a0 = (uint32_t)t0.x, a1 = (uint32_t)t1.x, b0 = (uint32_t)t0.y, b1 = (uint32_t)t1.y;
+					__builtin_amdgcn_sched_barrier(0);
+					const vp_f2 t2 = sum2(w2a, w2b, q20, q21, o);
+					const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
+					const uint32_t a2 = (uint32_t)t2.x, a3 = (uint32_t)t3.x, b2 = (uint32_t)t2.y, b3 = (uint32_t)t3.y;
+					__builtin_amdgcn_sched_barrier(0); // (the staging below needs 8 registers of its own: only once the products are dead)
+					// (a: frame j, b: frame j + 1; the greens halved)
+					if(j + 2 < nf) put((jj + 1) & 1, pre[j + 2 < RESAMPLE_FPT ? j + 2 : j], pre[j + 3 < RESAMPLE_FPT ? j + 3 : j + 1]);
+					const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
+					const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
+					store_flat(pxa, (uint32_t)j * fb_flat);
+					if(j + 1 < nf) store_flat(pxb, (uint32_t)(j + 1) * fb_flat);
+					if(agg) {
+						park_row(j, pxa);
+						park_row(j + 1, pxb);
+					}
+					if(j > 0) {
+						flush(j - 2);
+						flush(j - 1);
+					}
 					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 					__syncthreads();
 				}
-				flush(nf - 1);
+				const int last = (nf - 1) & ~1; // the last pair's records
+				flush(last);
+				if(last + 1 < nf) flush(last + 1);
 			};
 			// NEAREST: the boxes of all frames up front (as `run`), then four byte picks per pixel and frame
 			auto run_near = [&]() {
@@ -706,10 +722,9 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					if(se) __builtin_amdgcn_raw_buffer_store_b32(px4, rs_strip, voff_se, (uint32_t)j * fb_strip, 0);
 				}
 			};
-			// (two float-staged bodies in one instantiation cost 86 VGPRs instead of 68 -- five wavefronts per SIMD instead of seven: VARIANT 3 falls back to bytes)
-			const bool pair_ok = PAIR && !xclamp && wdw > 0 && wdw <= 64 && 4 * (64 / wdw) >= hr; // (8 ndw floats per buffer <= 2048: ndw <= STAGE_DW holds already)
+			// (two float-staged bodies in one instantiation cost 86 VGPRs instead of 70 -- five wavefronts per SIMD instead of seven: VARIANT 3 falls back to bytes)
 			if(NEAR) run_near();
-			else if(PAIR && pair_ok) run_pair();
+			else if(FP && !xclamp) run_fp();
 			else if(FLT) run_flt();
 			else if(ndw <= 256) run(std::integral_constant<int, 1>());
 			else run(std::integral_constant<int, STAGE_DW / 256>());
@@ -973,7 +988,7 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 	if(layout != VP_LAYOUT_BGR && qw >= 4 && (qw & 1) == 0 && batch >= 2 && span < 0x7fffffffu
 			&& ((reinterpret_cast<uintptr_t>(raw) | frame_bytes) & 3) == 0 && qw < 65536 && qh < 32768 && vp_div_up(fh, 4) <= 65535) {
 		const dim3 grid(vp_div_up(fw, 64), vp_div_up(fh, 4), vp_div_up(batch, RESAMPLE_FPT));
-		const int fs = ctx->tune.resample_float_stage; // 2 (default): aligned float pairs; 1: floats; 0: bytes (vp_ctx_tune "resample_float_stage")
+		const int fs = ctx->tune.resample_float_stage; // 2 (default): floats, two frames side by side; 1: floats; 0: bytes (vp_ctx_tune "resample_float_stage")
 		const int variant = sampler_mode == VP_SAMPLER_NEAREST ? 2 : (fs >= 2 ? 3 : fs == 1 ? 1 : 0);
 		// XCD-contiguous tile bands for large frames (measured at 2048x1536: HBM reads 1.38 -> 0.60 GB per 128 frames, time unchanged;
 		// at 640x480 the bands unbalance the XCDs: 87 -> 99 us, so small grids keep the plain mapping).  vp_ctx_tune "resample_xcd_bands" forces it.
