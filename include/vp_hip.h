@@ -101,7 +101,7 @@ const char* vp_last_error(void);
 int vp_device_count(void);
 const char* vp_device_name(VpContext* ctx);
 /* Result-neutral tuning (every value gives bit-identical output; the library reads no environment variable):
- *   "sat_workgroups_per_cu" 2..8 (0 = automatic, the default), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_float_stage" 0 / 1 / 2 (default 2: the staged Bayer kernel parks the footprint box in LDS as floats, two frames side by side; 1: floats; 0: bytes),
+ *   "sat_workgroups_per_cu" 2..8 (0 = automatic, the default), "resample_xcd_bands" -1 automatic / 0 / 1, "resample_groups_per_wg" 0..64 (default 0 = automatic: 16-frame groups a resampling workgroup takes with one set-up), "resample_float_stage" 0 / 1 / 2 (default 2: the staged Bayer kernel parks the footprint box in LDS as floats, two frames side by side; 1: floats; 0: bytes),
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "tail_emit_kernel" 0 / 1 (default 1: the walkers' survivors become records in a second
  *   launch, one workgroup per frame; 0: inside the walker), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel

@@ -460,7 +460,7 @@ def test_tuning_knobs_are_result_neutral(env, cfg):
     raws = dev(torch, np.stack([cfg.synth(5100 + i) for i in range(B)]))
     p = capi.frame_params(cfg, order=capi.ORDER_RASTER)
     want = None
-    for knobs in ({}, {"sat_halo_strips": 0}, {"sat_workgroups_per_cu": 2}, {"sat_workgroups_per_cu": 6}, {"resample_float_stage": 0}, {"resample_float_stage": 1}, {"resample_xcd_bands": 1},
+    for knobs in ({}, {"sat_halo_strips": 0}, {"sat_workgroups_per_cu": 2}, {"sat_workgroups_per_cu": 6}, {"resample_float_stage": 0}, {"resample_float_stage": 1}, {"resample_groups_per_wg": 1}, {"resample_groups_per_wg": 5}, {"resample_xcd_bands": 1},
                   {"resample_xcd_bands": 0, "tail_segment_rows": 16}, {"tail_segment_rows": 192, "sat_halo_strips": 0}, {"candidate_capacity": 8}):
         ctx = capi.Context(0, n_streams=1)
         try:

@@ -190,3 +190,57 @@ def test_placement_search_keeps_to_its_cap_and_reports_an_exhausted_budget(env):
         assert free1 >= free0 - (64 << 20), (free0, free1)  # every candidate went back
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("shift", [0.0, -0.45, 0.45], ids=["centred", "past_the_left_border", "past_the_right_border"])
+def test_resampling_frame_pairs_and_groups_per_workgroup(env, port, shift):
+    """k_resample_staged<., 3> (the default): the footprint box staged as floats of two frames side by side, both frames computed at once, a workgroup
+    taking several 16-frame groups with one set-up.  37 frames = groups of 16 + 16 + 5 (an odd last group: a half-filled last pair), every
+    "resample_groups_per_wg" setting and the older stage formats must give the same flat images, and frames on both sides of every group boundary must be
+    the oracle's.  `shift` moves the field window so that the left / right part of flat looks past the sensor border: there a footprint's two columns
+    clamp onto one cell (resampling.cl:50 with CLK_ADDRESS_CLAMP_TO_EDGE), which the frame-pair body reads from a copy of the border cell in a virtual
+    cell beside the box; the flat window also ends inside a tile there (clamped duplicate lanes)."""
+    capi, torch = env
+    base = cfgs.T_MID
+    cfg = base.with_(name=f"{base.name}_shift{shift}", off_x=base.off_x + shift * base.fw * base.field_scale) if shift else base
+    B, mm = 37, cfg.max_matches
+    raws = np.stack([cfg.synth(6200 + i) for i in range(B)])
+    d_raw = torch.from_numpy(raws).cuda()
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    want = {}
+    for k in (0, 15, 16, 31, 32, 35, 36):
+        s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+        port.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                   cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+        want[k] = s["flat"].copy()
+    if shift:  # the window really looks past the border: the outermost flat columns (nearly) repeat -- every footprint there is the border cell, only v still moves
+        col = 0 if shift < 0 else cfg.fw - 1
+        step = 1 if shift < 0 else -1
+        same = np.mean(np.all(want[0][:, col] == want[0][:, col + 8 * step], axis=-1))
+        inner = np.mean(np.all(want[0][:, cfg.fw // 2] == want[0][:, cfg.fw // 2 + 8], axis=-1))
+        assert same > inner + 0.3, (same, inner)
+    ref = None
+    for knobs in ({}, {"resample_groups_per_wg": 1}, {"resample_groups_per_wg": 3}, {"resample_groups_per_wg": 64}, {"resample_float_stage": 1}, {"resample_float_stage": 0},
+                  {"sat_halo_strips": 0, "resample_groups_per_wg": 2}):
+        ctx = capi.Context(0, n_streams=1)
+        try:
+            for k, v in knobs.items():
+                ctx.tune(k, v)
+            p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+            flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+            sat = torch.zeros((B, cfg.fh, cfg.fw), dtype=torch.int32, device="cuda")
+            m = torch.zeros((B, mm * 22), dtype=torch.uint8, device="cuda")
+            idx = torch.zeros((B, mm), dtype=torch.int32, device="cuda")
+            cnt = torch.full((B, 3), -3, dtype=torch.int32, device="cuda")
+            for _ in range(2):
+                ctx.frame(p, d_raw, B, flat, sat, m, cnt, idx=idx)
+            ctx.sync()
+            got = (flat.cpu().numpy(), sat.cpu().numpy(), cnt.cpu().numpy())
+        finally:
+            ctx.close()
+        for k, w in want.items():
+            assert np.array_equal(got[0][k], w), (knobs, "flat of frame", k)
+        if ref is None:
+            ref = got
+        else:  # the table (built from the strip records the resampling kernel wrote) and the counters too
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), knobs

@@ -112,6 +112,9 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 	} else if(k == "resample_xcd_bands") {
 		VP_REQUIRE(value >= -1 && value <= 1, "vp_ctx_tune: resample_xcd_bands takes -1 (automatic), 0 or 1");
 		ctx->tune.resample_xcd_bands = value;
+	} else if(k == "resample_groups_per_wg") {
+		VP_REQUIRE(value >= 0 && value <= 64, "vp_ctx_tune: resample_groups_per_wg %d: 0 (automatic) or 1..64", value);
+		ctx->tune.resample_groups_per_wg = value;
 	} else if(k == "resample_float_stage") {
 		VP_REQUIRE(value >= 0 && value <= 2, "vp_ctx_tune: resample_float_stage %d: 0 (bytes), 1 (floats) or 2 (floats, two frames side by side)", value);
 		ctx->tune.resample_float_stage = value;

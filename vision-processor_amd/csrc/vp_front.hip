@@ -409,10 +409,10 @@ __device__ __forceinline__ uint32_t wave_reduce_pk16(uint32_t v) {
 // floats of two frames side by side (run_fp) where the workgroup's footprints allow it, as bytes elsewhere (the tiles on the left / right image border).
 template<int LAYOUT, int VARIANT, bool NTS>
 __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restrict__ raw, const float2* __restrict__ map, uint8_t* __restrict__ flat,
-		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch, int xcd_map) {
+		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch, int xcd_map, int groups_per_wg) {
 	__shared__ __attribute__((aligned(16))) uint32_t stage[RESAMPLE_FPT][STAGE_DW];
 	__shared__ __attribute__((aligned(16))) uint32_t fp_rows[2][2][4][64]; // run_fp: the workgroup's 4 x 64 flat pixels of the two frames of a step (the strip records are gathered from them), double buffered
-	__shared__ uint32_t red[4][3];
+	__shared__ uint32_t red[4][2];
 	const unsigned bz = blockIdx.z;
 	// Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  A workgroup's box shares its 64/128-byte lines with the
 	// boxes left and right of it and two to four sensor rows with those above and below; with the plain mapping horizontal
@@ -429,7 +429,6 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 	const bool valid = gx < fw && gy < fh;
 	const float2 pos = map[(size_t)min(gy, fh - 1) * fw + min(gx, fw - 1)];
 	const float px = pos.x, py = pos.y;
-	const int f0 = (int)bz * RESAMPLE_FPT, f1 = min(batch, f0 + RESAMPLE_FPT);
 	const size_t npx = (size_t)fw * fh;
 	const uint32_t rowb = 2u * (uint32_t)qw;
 	{
@@ -449,21 +448,19 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 		const uint32_t lo_w = wave_reduce_pk16<false>(NEAR ? (uint32_t)(min(nca, ncb) >> 2) | ((uint32_t)min(ne, no) << 16) : (uint32_t)g.d0 | ((uint32_t)min(g.re0, g.ro0) << 16));
 		const uint32_t hi_w = wave_reduce_pk16<true>(NEAR ? (uint32_t)((max(nca, ncb) >> 2) + 1) | ((uint32_t)max(ne, no) << 16) : (uint32_t)(g.d0 + 2) | ((uint32_t)max(g.re1, g.ro1) << 16));
 		const int tid = threadIdx.y * 64 + threadIdx.x;
-		// (run_fp) does any pixel of the workgroup have a footprint whose second column is NOT the first one's right neighbour (clamp-to-edge at the image border)?
-		const bool xclamp_w = FP && __any(g.ia1 != g.ia0 + 1 || g.ib1 != g.ib0 + 1);
 		if(threadIdx.x == 0) {
 			red[threadIdx.y][0] = lo_w;
 			red[threadIdx.y][1] = hi_w;
-			red[threadIdx.y][2] = xclamp_w;
 		}
 		__syncthreads();
 		const uint32_t lo = pk16_min(pk16_min(red[0][0], red[1][0]), pk16_min(red[2][0], red[3][0]));
 		const uint32_t hi = pk16_max(pk16_max(red[0][1], red[1][1]), pk16_max(red[2][1], red[3][1]));
-		const bool xclamp = (red[0][2] | red[1][2] | red[2][2] | red[3][2]) != 0;
 		const int cmin = (int)(lo & 0xFFFF), rmin = (int)(lo >> 16), cmax = (int)(hi & 0xFFFF), rmax = (int)(hi >> 16);
 		const int wdw = cmax - cmin, hr = rmax - rmin + 1, ndw = wdw * hr;
+		// The workgroup's first frame group (up to RESAMPLE_FPT frames [f0, f1)); run_fp goes on to the next groups_per_wg - 1 by itself.
+		auto group = [&](const int f0, const int f1) {
 		const size_t raw_span = (size_t)(f1 - f0) * src_frame_bytes, flat_span = (size_t)(f1 - f0) * npx * 4;
-		if(ndw <= STAGE_DW && raw_span < 0x7fffffffu && flat_span < 0x7fffffffu && (size_t)(f1 - f0) * strips.frame_words * 4 < 0x7fffffffu) {
+		if((FP ? hr * (wdw + 2) : ndw) <= STAGE_DW && raw_span < 0x7fffffffu && flat_span < 0x7fffffffu && (size_t)(f1 - f0) * strips.frame_words * 4 < 0x7fffffffu) {
 			// buffer addressing: descriptor in SGPRs (rebased to this frame group), 32-bit per-lane offset, per-frame scalar
 			// offset -- no 64-bit VALU address arithmetic inside the frame loop
 			const __amdgpu_buffer_rsrc_t rs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)f0 * src_frame_bytes, 0, (int)raw_span, 0x00020000);
@@ -594,27 +591,42 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			// (v_pk_mul_f32 taking one half of a weight pair for both lanes, v_pk_add_f32), in the order of the sampler definition.  Per pixel and frame: 8 LDS
 			// reads instead of 16, 14 instead of 17 instructions for the four sums, half a barrier; per staged dword one ds_write_b128 per plane and frame PAIR.
 			// [First built with CELL pairs (T[k], T[k+1]) per frame: every texel stored twice, the neighbour's dword fetched by a DPP wave shift, whole box rows per
-			// staging wavefront; 1 % slower than this and more conditions.]  Condition (workgroup-uniform; otherwise the byte stage, same results): no footprint of
-			// the workgroup is clamped in x -- the second column's texel is read at + 8 bytes from the first one's address register -- which holds for all tiles
-			// but those on the left / right image border.
+			// staging wavefront; 1 % slower than this and more conditions.]
+			// The second column's texel is read at + 8 bytes from the first one's address register, so a footprint must be two NEIGHBOURING cells -- also where
+			// clamp-to-edge folds it onto one (sample<>(): i0 = clamp(fu), i1 = clamp(fu + 1)): a box row carries two spare cells on either side, and a box that
+			// touches the left / right sensor border gets a copy of cell 0 in virtual cell -1 / of cell qw - 1 in virtual cell qw.  The pair (i0v, i0v + 1) with
+			// i0v = clamp(fu, -1, qw - 1) then reads exactly (T[i0], T[i1]) for every fu.
+			// The loop over the workgroup's frame groups sits BELOW the set-up (coordinate, footprints, box, weights, addresses: about a third of the kernel's VALU
+			// instructions at one group per workgroup), which is paid once for all of them.
 			auto run_fp = [&]() {
-				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: 2 wdw cells x (frame f, frame f + 1) | plane B likewise]
-				const int RP = 8 * wdw;                             // floats per box row
+				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: (2 wdw + 4) cells x (frame f, frame f + 1) | plane B likewise]
+				const int PL = 4 * wdw + 8, RP = 2 * PL;            // floats per plane of a box row, per box row
 				const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
 				const int own = tid < ndw ? tid : 0, orow = (int)(((float)own + 0.5f) * inv_wdw), ocol = own - orow * wdw;
 				const uint32_t goff = (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol);
-				float* wa = F + orow * RP + 4 * ocol; // cells 2 ocol, 2 ocol + 1 of plane A; plane B 4 wdw floats on
-				uint32_t pre[RESAMPLE_FPT];
-#pragma unroll
-				for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_raw, goff, (uint32_t)min(j, nf - 1) * fb_raw, 0);
+				float* wa = F + orow * RP + 4 * ocol + 4; // real cells 2 ocol, 2 ocol + 1 of plane A (behind the two spare cells); plane B PL floats on
+				const bool pad_l = cmin == 0, pad_r = 2 * cmax == qw;                     // workgroup-uniform: the box touches the left / right sensor border
+				const bool own_l = tid < ndw && ocol == 0, own_r = tid < ndw && ocol == wdw - 1; // the threads that hold cell 0 / cell qw - 1 of a box row
 				auto put = [&](int buf, uint32_t v0, uint32_t v1) { // frames f (v0) and f + 1 (v1) of this thread's dword
-					if(tid < ndw) {
-						*reinterpret_cast<vp_f4*>(wa + buf * 2048) = vp_f4{(float)(v0 & 0xFF), (float)(v1 & 0xFF), (float)((v0 >> 16) & 0xFF), (float)((v1 >> 16) & 0xFF)};
-						*reinterpret_cast<vp_f4*>(wa + buf * 2048 + 4 * wdw) = vp_f4{(float)((v0 >> 8) & 0xFF), (float)((v1 >> 8) & 0xFF), (float)(v0 >> 24), (float)(v1 >> 24)};
+					float* w = wa + buf * 2048;
+					{ // plane A: even sensor columns (one plane at a time: four conversion results alive, not eight)
+						const float a0 = (float)(v0 & 0xFF), a1 = (float)(v1 & 0xFF), c0 = (float)((v0 >> 16) & 0xFF), c1 = (float)((v1 >> 16) & 0xFF);
+						if(tid < ndw) *reinterpret_cast<vp_f4*>(w) = vp_f4{a0, a1, c0, c1};
+						if(pad_l && own_l) *reinterpret_cast<vp_f2*>(w - 2) = vp_f2{a0, a1}; // virtual cell -1 := cell 0
+						if(pad_r && own_r) *reinterpret_cast<vp_f2*>(w + 4) = vp_f2{c0, c1}; // virtual cell qw := cell qw - 1
+					}
+					__builtin_amdgcn_sched_barrier(0);
+					{ // plane B: odd sensor columns
+						const float b0 = (float)((v0 >> 8) & 0xFF), b1 = (float)((v1 >> 8) & 0xFF), d0 = (float)(v0 >> 24), d1 = (float)(v1 >> 24);
+						if(tid < ndw) *reinterpret_cast<vp_f4*>(w + PL) = vp_f4{b0, b1, d0, d1};
+						if(pad_l && own_l) *reinterpret_cast<vp_f2*>(w + PL - 2) = vp_f2{b0, b1};
+						if(pad_r && own_r) *reinterpret_cast<vp_f2*>(w + PL + 4) = vp_f2{d0, d1};
 					}
 				};
-				// cell i of plane A sits at float 2 (i - 2 cmin) of its box row, plane B 4 wdw floats on; the footprint's second column is the next cell ([1])
-				const int pa = 2 * (g.ia0 - 2 * cmin), pb = 2 * (g.ib0 - 2 * cmin) + 4 * wdw;
+				// the first cell of a footprint in virtual coordinates: the clamped pair (0, 0) is (-1, 0), the clamped pair (qw - 1, qw - 1) is (qw - 1, qw)
+				const int ia = g.ia0 == g.ia1 && g.ia0 == 0 ? -1 : g.ia0, ib = g.ib0 == g.ib1 && g.ib0 == 0 ? -1 : g.ib0;
+				// cell i of plane A sits at float 2 (i - 2 cmin + 2) of its box row, plane B PL floats on; the footprint's second column is the next cell ([1])
+				const int pa = 2 * (ia - 2 * cmin + 2), pb = 2 * (ib - 2 * cmin + 2) + PL;
 				const int r0 = (g.re0 - rmin) * RP, r1 = (g.re1 - rmin) * RP, r2 = (g.ro0 - rmin) * RP, r3 = (g.ro1 - rmin) * RP;
 				const vp_f2* q00 = reinterpret_cast<const vp_f2*>(F + r0 + pa); const vp_f2* q01 = reinterpret_cast<const vp_f2*>(F + r1 + pa);
 				const vp_f2* q10 = reinterpret_cast<const vp_f2*>(F + r0 + pb); const vp_f2* q11 = reinterpret_cast<const vp_f2*>(F + r1 + pb);
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				const vp_f2 w2a = vp_f2{(oxa * oyb) * h2, (g.xa * oyb) * h2}, w2b = vp_f2{(oxa * g.yb) * h2, (g.xa * g.yb) * h2};
 				const vp_f2 w3a = vp_f2{(oxb * oyb) * h3, (g.xb * oyb) * h3}, w3b = vp_f2{(oxb * g.yb) * h3, (g.xb * g.yb) * h3};
 				// (volatile: two 8-byte reads 8 bytes apart must NOT be merged into one ds_read2_b64 -- that costs 8 LDS cycles against 2 + 2, MI355X_MICROARCH.md, LDS)
-				auto sum2 = [&](vp_f2 wa, vp_f2 wb, const vp_f2* row0, const vp_f2* row1, int o) { // both frames: w00 t00 + w10 t10 + w01 t01 + w11 t11, in that order
+				auto sum2 = [&](vp_f2 wa_, vp_f2 wb_, const vp_f2* row0, const vp_f2* row1, int o) { // both frames: w00 t00 + w10 t10 + w01 t01 + w11 t11, in that order
 					typedef __attribute__((address_space(3))) const volatile vp_f2 lds_f2;
 					lds_f2* v0 = (lds_f2*)(row0 + o);
 					lds_f2* v1 = (lds_f2*)(row1 + o);
@@ -639,10 +651,10 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					// one half of a weight pair times both frames' texels.  Written as asm because the compiler, given a broadcast, keeps 16 (w, w) register pairs alive
 					// instead of selecting the half in the instruction (op_sel / op_sel_hi: [weight half for lane 0, texel lo], [weight half for lane 1, texel hi])
 					vp_f2 m00, m10, m01, m11;
-					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m00) : "v"(wa), "v"(t00));
-					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m10) : "v"(wa), "v"(t10));
-					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m01) : "v"(wb), "v"(t01));
-					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m11) : "v"(wb), "v"(t11));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m00) : "v"(wa_), "v"(t00));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m10) : "v"(wa_), "v"(t10));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(m01) : "v"(wb_), "v"(t01));
+					asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m11) : "v"(wb_), "v"(t11));
 					vp_f2 t = m00 + m10;
 					t = t + m01;
 					t = t + m11;
@@ -652,52 +664,72 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				const bool agg = strips.base != nullptr;
 				const uint32_t voff_rec = 4u * (((uint32_t)bxi * shp + (uint32_t)byi * 4u) * 2u * so + (uint32_t)threadIdx.x);
 				const bool rec_lane = threadIdx.x < 8 * strips.o;
-				const int rec_row = (int)threadIdx.x / (2 * (int)so), rec_e = (int)threadIdx.x - rec_row * 2 * (int)so;
+				const int rec_row = (int)(((float)threadIdx.x + 0.5f) * __builtin_amdgcn_rcpf((float)(2 * (int)so))), rec_e = (int)threadIdx.x - rec_row * 2 * (int)so; // lane / 2o (2o <= 8: exact)
 				const uint32_t* rec_src = &fp_rows[0][0][rec_lane ? rec_row : 0][rec_lane ? (rec_e < (int)so ? rec_e : 64 - 2 * (int)so + rec_e) : 0];
 				const uint32_t row_m0 = (uint32_t)(uintptr_t)&fp_rows[0][0][wave][0];
 				auto park_row = [&](int j, uint32_t px4) { // frame j: buffer (j >> 1) & 1, half j & 1 (asm: hipcc neither counts the LDS store -- the s_waitcnt before the step's barrier covers it -- nor pads the hazard: an SALU write of M0 needs one wait state before an LDS add-TID instruction)
 					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(px4), "s"(__builtin_amdgcn_readfirstlane((int)(row_m0 + (uint32_t)(((j >> 1) & 1) * 2 + (j & 1)) * 1024u))) : "m0", "memory");
 				};
-				auto flush = [&](int j) {
-					if(agg && wave == (j & 3) && rec_lane)
-						__builtin_amdgcn_raw_buffer_store_b32(rec_src[(((j >> 1) & 1) * 2 + (j & 1)) * 256], rs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
-				};
-				put(0, pre[0], pre[1]);
-				__syncthreads();
+				for(int gi = 0; gi < groups_per_wg; gi++) {
+					const int g0 = f0 + gi * RESAMPLE_FPT; // this group's first frame
+					if(g0 >= batch) break;
+					const int nfg = min(batch - g0, RESAMPLE_FPT);
+					// this group's buffer windows (32-bit lane offsets + a per-frame scalar offset; the spans were checked for a full group)
+					const __amdgpu_buffer_rsrc_t grs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)g0 * src_frame_bytes, 0, (int)((size_t)nfg * src_frame_bytes), 0x00020000);
+					const __amdgpu_buffer_rsrc_t grs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)g0 * npx * 4, 0, (int)((size_t)nfg * npx * 4), 0x00020000);
+					const __amdgpu_buffer_rsrc_t grs_strip = __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)g0 * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
+							(int)((size_t)nfg * strips.frame_words * 4), 0x00020000);
+					auto gstore = [&](uint32_t px4, uint32_t soff) { __builtin_amdgcn_raw_buffer_store_b32(px4, grs_flat, voff_out, soff, NTS ? 2 : 0); };
+					auto flush = [&](int j) {
+						if(agg && wave == (j & 3) && rec_lane)
+							__builtin_amdgcn_raw_buffer_store_b32(rec_src[(((j >> 1) & 1) * 2 + (j & 1)) * 256], grs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
+					};
+					// the boxes of all the group's frames are requested up front (no store of THIS group is in flight yet; what is left of the previous group's
+					// stores is drained by the first wait below: once per group, not per frame)
+					uint32_t pre[RESAMPLE_FPT];
 #pragma unroll
-				for(int jj = 0; jj < RESAMPLE_FPT / 2; jj++) {
-					const int j = 2 * jj;
-					if(j >= nf) break;
-					const int o = (jj & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
-					// (two channels' texels in flight at a time: all sixteen 8-byte reads up front cost 24 more VGPRs -- five wavefronts per SIMD instead of seven)
-					const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
-					const vp_f2 t1 = sum2(w1a, w1b, q10, q11, o);
-					const uint32_t a0 = (uint32_t)t0.x, a1 = (uint32_t)t1.x, b0 = (uint32_t)t0.y, b1 = (uint32_t)t1.y;
-					__builtin_amdgcn_sched_barrier(0);
-					const vp_f2 t2 = sum2(w2a, w2b, q20, q21, o);
-					const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
-					const uint32_t a2 = (uint32_t)t2.x, a3 = (uint32_t)t3.x, b2 = (uint32_t)t2.y, b3 = (uint32_t)t3.y;
-					__builtin_amdgcn_sched_barrier(0); // (the staging below needs 8 registers of its own: only once the products are dead)
-					// (a: frame j, b: frame j + 1; the greens halved)
-					if(j + 2 < nf) put((jj + 1) & 1, pre[j + 2 < RESAMPLE_FPT ? j + 2 : j], pre[j + 3 < RESAMPLE_FPT ? j + 3 : j + 1]);
-					const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
-					const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
-					store_flat(pxa, (uint32_t)j * fb_flat);
-					if(j + 1 < nf) store_flat(pxb, (uint32_t)(j + 1) * fb_flat);
-					if(agg) {
-						park_row(j, pxa);
-						park_row(j + 1, pxb);
-					}
-					if(j > 0) {
-						flush(j - 2);
-						flush(j - 1);
-					}
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(grs_raw, goff, (uint32_t)min(j, nfg - 1) * fb_raw, 0);
+					if(gi) __syncthreads(); // the previous group's last stage reads are done before this group's first frames are parked
+					put(0, pre[0], pre[1]);
 					__syncthreads();
+#pragma unroll
+					for(int jj = 0; jj < RESAMPLE_FPT / 2; jj++) {
+						const int j = 2 * jj;
+						if(j >= nfg) break;
+						const int o = (jj & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
+						// (two channels' texels in flight at a time: all sixteen 8-byte reads up front cost 24 more VGPRs)
+						const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
+						const uint32_t a0 = (uint32_t)t0.x, b0 = (uint32_t)t0.y; // a: frame j, b: frame j + 1; the greens halved
+						__builtin_amdgcn_sched_barrier(0);
+						const vp_f2 t1 = sum2(w1a, w1b, q10, q11, o);
+						const uint32_t a1 = (uint32_t)t1.x, b1 = (uint32_t)t1.y;
+						__builtin_amdgcn_sched_barrier(0);
+						const vp_f2 t2 = sum2(w2a, w2b, q20, q21, o);
+						const uint32_t a2 = (uint32_t)t2.x, b2 = (uint32_t)t2.y;
+						__builtin_amdgcn_sched_barrier(0);
+						const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
+						const uint32_t a3 = (uint32_t)t3.x, b3 = (uint32_t)t3.y;
+						__builtin_amdgcn_sched_barrier(0); // (the staging below needs registers of its own: only once the products are dead)
+						if(j + 2 < nfg) put((jj + 1) & 1, pre[j + 2 < RESAMPLE_FPT ? j + 2 : j], pre[j + 3 < RESAMPLE_FPT ? j + 3 : j + 1]);
+						const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
+						const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
+						gstore(pxa, (uint32_t)j * fb_flat);
+						if(j + 1 < nfg) gstore(pxb, (uint32_t)(j + 1) * fb_flat);
+						if(agg) {
+							park_row(j, pxa);
+							park_row(j + 1, pxb);
+						}
+						if(j > 0) {
+							flush(j - 2);
+							flush(j - 1);
+						}
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						__syncthreads();
+					}
+					const int last = (nfg - 1) & ~1; // the last pair's records
+					flush(last);
+					if(last + 1 < nfg) flush(last + 1);
 				}
-				const int last = (nf - 1) & ~1; // the last pair's records
-				flush(last);
-				if(last + 1 < nf) flush(last + 1);
 			};
 			// NEAREST: the boxes of all frames up front (as `run`), then four byte picks per pixel and frame
 			auto run_near = [&]() {
@@ -724,13 +756,12 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			};
 			// (two float-staged bodies in one instantiation cost 86 VGPRs instead of 70 -- five wavefronts per SIMD instead of seven: VARIANT 3 falls back to bytes)
 			if(NEAR) run_near();
-			else if(FP && !xclamp) run_fp();
+			else if(FP) run_fp();
 			else if(FLT) run_flt();
 			else if(ndw <= 256) run(std::integral_constant<int, 1>());
 			else run(std::integral_constant<int, STAGE_DW / 256>());
 			return;
 		}
-	}
 	if(!valid) return;
 	uint32_t* out = reinterpret_cast<uint32_t*>(flat) + (size_t)gy * fw + gx;
 	if(VARIANT == 2) {
@@ -753,6 +784,11 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 		const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
 		out[(size_t)f * npx] = px4;
 		emit_strip(strips, f, gx, gy, px4);
+	}
+		}; // group
+		// (run_fp loops over the workgroup's groups itself, below its set-up; the other bodies take one group per workgroup: the host passes groups_per_wg = 1)
+		const int f0 = (int)bz * groups_per_wg * RESAMPLE_FPT;
+		group(f0, min(batch, f0 + RESAMPLE_FPT));
 	}
 }
 
@@ -994,10 +1030,15 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 		// at 640x480 the bands unbalance the XCDs: 87 -> 99 us, so small grids keep the plain mapping).  vp_ctx_tune "resample_xcd_bands" forces it.
 		const int xcd_map = ctx->tune.resample_xcd_bands >= 0 ? ctx->tune.resample_xcd_bands : (grid.x * grid.y >= 4096u);
 		const bool flat_nt = (size_t)fw * fh * 4 * batch > (size_t(112) << 20); // see store_flat in k_resample_staged
+		// frame groups per workgroup: the set-up is paid once for all of them; only where enough workgroups remain to fill the chip several times over
+		const int n_groups = (int)vp_div_up(batch, RESAMPLE_FPT);
+		// (measured at 256 frames: 1 -> 1367, 2 -> 1305, 4 -> 1304, 8 -> 1308 us per launch; only the frame-pair body loops over groups)
+		const int gpw = variant != 3 ? 1 : std::min(ctx->tune.resample_groups_per_wg > 0 ? ctx->tune.resample_groups_per_wg : 2, n_groups);
+		const dim3 gridg(grid.x, grid.y, vp_div_up(n_groups, gpw));
 #define VP_RST(L, V) \
 		do { \
-			if(flat_nt) k_resample_staged<L, V, true><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map); \
-			else k_resample_staged<L, V, false><<<grid, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map); \
+			if(flat_nt) k_resample_staged<L, V, true><<<gridg, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map, gpw); \
+			else k_resample_staged<L, V, false><<<gridg, block, 0, s>>>(raw, m2, flat, qw, qh, fw, fh, frame_bytes, strips, batch, xcd_map, gpw); \
 		} while(0)
 		if(layout == VP_LAYOUT_RGGB) {
 			if(variant == 3) VP_RST(VP_LAYOUT_RGGB, 3);
