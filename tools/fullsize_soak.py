@@ -1,4 +1,4 @@
-"""Full-size soak of the timed launch shape: 128 resident cfg2 frames, their ORDER in the batch reshuffled every iteration (so every frame meets every
+"""Full-size soak of the timed launch shape: feeds.BENCH_FRAMES_PER_STEP (256) resident cfg2 frames, their ORDER in the batch reshuffled every iteration (so every frame meets every
 slot, frame-group position and neighbour), vp_frame with the bench's parameters on placement-checked buffers; per-frame checksums of flat, the table,
 counters and records must not depend on the position, and a few frames are compared with the CPU oracle outright.  GPU; tools only.
 usage: fullsize_soak.py [SECONDS=120] [tiled|local]"""
@@ -12,7 +12,7 @@ import oracle as O
 vp = load(); capi = vp.load_capi()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 local = len(sys.argv) > 2 and sys.argv[2] == "local"
-cfg = vp.configs.ALL["cfg2_2048x1536_rggb"]; B, mm = 128, cfg.max_matches
+cfg = vp.configs.ALL["cfg2_2048x1536_rggb"]; B, mm = vp.feeds.BENCH_FRAMES_PER_STEP, cfg.max_matches
 with ThreadPoolExecutor(16) as ex:
     raws = np.stack(list(ex.map(cfg.synth, [vp.feeds.feed_seed(3, i) for i in range(B)])))
 base = torch.from_numpy(raws).cuda()
