@@ -244,3 +244,35 @@ def test_resampling_frame_pairs_and_groups_per_workgroup(env, port, shift):
             ref = got
         else:  # the table (built from the strip records the resampling kernel wrote) and the counters too
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), knobs
+
+
+def test_resampling_groups_per_workgroup_on_the_unstaged_path(env, port):
+    """A geometry whose 64 x 4-pixel tiles have footprint boxes too large for the LDS stage (one flat pixel spans four sensor cells: a box of ~130 x 20
+    dwords) sends every workgroup of the default resampling kernel down its per-pixel path -- which must then cover ALL the 16-frame groups the workgroup
+    was given (two by default), not only the first: frames 16..36 of a 37-frame launch against the oracle."""
+    capi, torch = env
+    base = cfgs.T_MID
+    fs = base.field_scale * 8.0
+    cfg = base.with_(name=base.name + "_coarse", field_scale=fs, off_x=-base.fw / 2 * fs, off_y=-base.fh / 2 * fs)
+    B, mm = 37, cfg.max_matches
+    raws = np.stack([cfg.synth(6400 + i) for i in range(B)])
+    d_raw = torch.from_numpy(raws).cuda()
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+        for gpw in (0, 1, 3):
+            ctx.tune("resample_groups_per_wg", gpw)
+            flat.zero_()
+            torch.cuda.synchronize()
+            ctx.resample_map(cfg.model(), cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, m := torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda"))
+            ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, m, cfg.sampler_mode, cfg.fw, cfg.fh, B, flat)
+            ctx.sync()
+            got = flat.cpu().numpy()
+            for k in (0, 15, 16, 31, 32, 36):
+                s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
+                port.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                           cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)
+                assert np.array_equal(got[k], s["flat"]), (gpw, k)
+    finally:
+        ctx.close()

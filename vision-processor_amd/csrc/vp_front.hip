@@ -778,7 +778,8 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 		return;
 	}
 	const Bayer4Geom gd = bayer4_geom(px, py, qw, qh);
-	for(int f = f0; f < f1; f++) {
+	const int f1d = min(batch, f0 + groups_per_wg * RESAMPLE_FPT); // every pixel fetches its own windows: ALL the workgroup's groups (only run_fp loops over them itself)
+	for(int f = f0; f < f1d; f++) {
 		uint32_t p[4];
 		bayer4_eval(raw + (size_t)f * src_frame_bytes, gd, p);
 		const uint32_t px4 = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack(p[0], p[1] / 2 + p[2] / 2, p[3]) : drgb_pack(p[1], p[0] / 2 + p[3] / 2, p[2]);
