@@ -156,11 +156,13 @@ static int stream_edge(VpContext* ctx, hipStream_t producer, int producer_device
 	VP_REQUIRE(!(producer == consumer), "%s: both sides are the same stream (already ordered)", what);
 	VP_CHECK_HIP(hipSetDevice(producer_device)); // an event is recorded on a stream of the device it was created on
 	hipEvent_t ev = nullptr;
-	VP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-	hipError_t e = hipEventRecord(ev, producer);
-	if(e == hipSuccess) e = hipStreamWaitEvent(consumer, ev, 0);
-	(void)hipEventDestroy(ev); // released by the runtime once the recorded work has completed
-	(void)hipSetDevice(ctx->device);
+	hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+	if(e == hipSuccess) {
+		e = hipEventRecord(ev, producer);
+		if(e == hipSuccess) e = hipStreamWaitEvent(consumer, ev, 0);
+		(void)hipEventDestroy(ev); // released by the runtime once the recorded work has completed
+	}
+	(void)hipSetDevice(ctx->device); // whatever happened: the calling thread is left on the context's device
 	if(e != hipSuccess) {
 		vp_set_error("%s failed: %s", what, hipGetErrorString(e));
 		return VP_ERR_HIP;
