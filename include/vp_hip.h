@@ -137,7 +137,8 @@ int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int wri
  * 3.8-4.4 TB/s zero-fill; reads are not affected), decided by where the allocation landed.  The reference allocates its images once and keeps them
  * (OpenCL::acquire pool, opencl.cpp:108-122; CLArray, opencl.cpp:137-159), so the draw is made once: vp_malloc_device_placed allocates up to
  * "placement_candidates" (vp_ctx_tune, default 96) blocks without freeing, times a zero-fill of each (vp_probe_stream), hands out the `count`
- * fastest (dptrs[0] the fastest) and frees the rest.  It stops early once `count` blocks write at 0.70 or more of the read-stream rate it measured on
+ * fastest (dptrs[0] the fastest) and frees the rest.  It stops early once `count` blocks (vp_frame_buffers_create: ONE, the table's -- flat is written by a kernel that is not HBM-bound and only read by the
+ * SAT pass, and reads do not depend on the placement) write at 0.70 or more of the read-stream rate it measured on
  * the first candidate (a ratio of two measurements of this device, not an MI355X constant: fast blocks reach 0.74-0.81, slow ones 0.57-0.66), or once
  * sixteen candidates lie within 6 % of each other; it never holds more than half of the free device memory and a quarter of the device, or "placement_max_mib" MiB (vp_ctx_tune,
  * default 0 = that rule), and it asks the device before every candidate and stops while an eighth of the device is still free, so that a second context or
@@ -148,6 +149,7 @@ typedef struct {
 	float best_gbs, worst_gbs;  /* over the candidates probed for the request */
 	int32_t candidates;         /* blocks allocated and probed */
 	int32_t selected;           /* 0 = plain hipMalloc; chosen among candidates: 1 = the search met its stop criterion, 2 = it ran out of candidates, bytes or memory first */
+	float fast_gbs;             /* the write rate that counts as fast on this device (0.70 x its read-stream rate; 0 when nothing was probed): write_gbs below it = a slow block */
 } VpPlacement;
 int vp_malloc_device_placed(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info /* count entries, or NULL */);
 int vp_copy_h2d(VpContext* ctx, int stream, void* dst_d, const void* src_h, size_t bytes);

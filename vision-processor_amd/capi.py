@@ -39,13 +39,13 @@ class VpFrameBuffers(C.Structure):
 
 
 class VpPlacement(C.Structure):
-    _fields_ = [("write_gbs", C.c_float), ("best_gbs", C.c_float), ("worst_gbs", C.c_float), ("candidates", C.c_int32), ("selected", C.c_int32)]
+    _fields_ = [("write_gbs", C.c_float), ("best_gbs", C.c_float), ("worst_gbs", C.c_float), ("candidates", C.c_int32), ("selected", C.c_int32), ("fast_gbs", C.c_float)]
 
     def as_dict(self):
         d = {"write_gbs": round(self.write_gbs, 1), "best_gbs": round(self.best_gbs, 1), "worst_gbs": round(self.worst_gbs, 1), "candidates": int(self.candidates),
-             "selected": bool(self.selected), "search": {0: "none", 1: "criterion met", 2: "budget exhausted"}.get(int(self.selected), "?")}
-        if int(self.selected) == 2:  # the best block seen was kept although no candidate reached the write rate of a fast block: a run on it is a slow draw, not the kernel
-            d["warning"] = "placement search ran out of candidates, bytes or memory before a fast block turned up: expect the SAT pass 5-15 % slower than on a fast block"
+             "selected": bool(self.selected), "search": {0: "none", 1: "criterion met", 2: "budget exhausted"}.get(int(self.selected), "?"), "fast_gbs": round(self.fast_gbs, 1)}
+        if int(self.selected) == 2 and self.write_gbs < self.fast_gbs:  # the search ended on its budget AND this block is a slow one: a run on it is a slow draw, not the kernel
+            d["warning"] = "placement search ran out of candidates, bytes or memory and this block writes below the device's fast rate: expect the SAT pass 5-15 % slower on it as a table"
         return d
 
 

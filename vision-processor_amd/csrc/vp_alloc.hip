@@ -75,7 +75,8 @@ extern "C" int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t byt
 // It never holds more than "placement_max_mib" (vp_ctx_tune; 0 = half of the free memory, at most a quarter of the device) at once and stops while an
 // eighth of the device is still free: a second context or process on the same GPU keeps room.  VpPlacement.selected says how it ended: 1 = criterion met, 2 = budget (candidates or bytes) or memory ran out first and the best blocks seen
 // were kept.
-int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info) {
+// need_fast: how many of the `count` blocks must be fast for the search to stop (0 = all of them)
+int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void** dptrs, VpPlacement* info, int need_fast = 0) {
 	VP_CHECK_HIP(hipSetDevice(ctx->device));
 	for(int i = 0; i < count; i++) dptrs[i] = nullptr;
 	const int budget = ctx->tune.placement_candidates;
@@ -140,7 +141,7 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 		cands.push_back({p, gbs});
 		if(select) {
 			n_fast += fast_gbs > 0.f && gbs >= fast_gbs;
-			if(n_fast >= count) {
+			if(n_fast >= (need_fast > 0 ? need_fast : count)) {
 				met = true;
 				break;
 			}
@@ -160,7 +161,7 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 	std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.gbs > b.gbs; });
 	for(int i = 0; i < count; i++) {
 		dptrs[i] = cands[i].p;
-		if(info) info[i] = VpPlacement{cands[i].gbs, cands.front().gbs, cands.back().gbs, (int32_t)cands.size(), select ? (met ? 1 : 2) : 0};
+		if(info) info[i] = VpPlacement{cands[i].gbs, cands.front().gbs, cands.back().gbs, (int32_t)cands.size(), select ? (met ? 1 : 2) : 0, select ? fast_gbs : 0.f};
 	}
 	for(size_t i = count; i < cands.size(); i++) (void)hipFree(cands[i].p);
 	return VP_OK;
@@ -193,18 +194,17 @@ extern "C" int vp_frame_buffers_create(VpContext* ctx, const VpFrameParams* p, i
 		rc = vp_malloc_device(ctx, bytes, dst);
 		if(rc == VP_OK) slab->blocks.push_back(*dst);
 	};
-	// the two image-sized buffers the path WRITES every frame are the ones whose placement matters: the fastest-writing candidate becomes the
-	// table (8 B/px pass, HBM-bound), the next one flat (written by the VALU-bound resampling kernel)
-	void* big[2] = {nullptr, nullptr};
-	const int n_big = local ? 1 : 2;
-	rc = vp_malloc_device_placed_impl(ctx, npx * 4, n_big, big, slab->placement);
-	if(rc == VP_OK) {
-		for(int i = 0; i < n_big; i++) slab->blocks.push_back(big[i]);
-		if(local) {
-			slab->buffers.flat = static_cast<uint8_t*>(big[0]);
-			slab->placement[1] = slab->placement[0];
-			memset(&slab->placement[0], 0, sizeof(VpPlacement));
-		} else {
+	// the one image-sized buffer whose placement matters is the TABLE (written once per frame by the HBM-bound 8 B/px pass): the fastest-writing candidate
+	// becomes the table, the next one flat -- which is written by the resampling kernel (not HBM-bound) and only read by the SAT pass (reads do not depend
+	// on the placement), so one fast block ends the search.  VP_SAT_LOCAL has no table: flat is a plain block.
+	if(local) {
+		plain(npx * 4, reinterpret_cast<void**>(&slab->buffers.flat));
+	} else {
+		void* big[2] = {nullptr, nullptr};
+		rc = vp_malloc_device_placed_impl(ctx, npx * 4, 2, big, slab->placement, 1);
+		if(rc == VP_OK) {
+			slab->blocks.push_back(big[0]);
+			slab->blocks.push_back(big[1]);
 			slab->buffers.sat = static_cast<int32_t*>(big[0]);
 			slab->buffers.flat = static_cast<uint8_t*>(big[1]);
 		}

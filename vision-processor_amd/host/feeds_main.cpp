@@ -225,7 +225,7 @@ int main(int argc, char** argv) {
 		int exhausted = 0;
 		for(int s = 0; s < 2; s++) {
 			CK(vp_frame_buffers_placement(slab[s], &pl[s], nullptr));
-			exhausted += pl[s].selected == 2;
+			exhausted += pl[s].selected == 2 && pl[s].write_gbs < pl[s].fast_gbs;
 		}
 		printf(", \"placement\": {\"sat_write_gbs\": [%.0f, %.0f], \"candidates\": [%d, %d]", pl[0].write_gbs, pl[1].write_gbs, pl[0].candidates, pl[1].candidates);
 		if(exhausted) {

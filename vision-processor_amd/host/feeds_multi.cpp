@@ -351,7 +351,7 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 	int exhausted = 0;
 	for(int g = 0; g < N; g++) {
 		const int sel = dev[g].place[0].selected;
-		exhausted += sel == 2;
+		exhausted += sel == 2 && dev[g].place[0].write_gbs < dev[g].place[0].fast_gbs;
 		printf("%s\"%s\"", g ? ", " : "", sel == 1 ? "criterion met" : sel == 2 ? "budget exhausted" : "none");
 	}
 	printf("]");
