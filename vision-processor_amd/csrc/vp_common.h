@@ -52,7 +52,7 @@ struct VpTuning {
 #ifndef VP_RS_GPW_DEFAULT
 #define VP_RS_GPW_DEFAULT 0
 #endif
-	int resample_groups_per_wg = VP_RS_GPW_DEFAULT; // staged Bayer resampling (frame-pair stage): consecutive 16-frame groups one workgroup takes with ONE set-up (coordinate, footprints, box, weights); 0 = automatic (2)
+	int resample_groups_per_wg = VP_RS_GPW_DEFAULT; // staged Bayer resampling (frame-pair stage): consecutive 16-frame groups one workgroup takes with ONE set-up (coordinate, footprints, box, weights); 0 = automatic (4)
 	int resample_bgr_staged = 1;   // BGR8 sensors: staged kernel (1) or the generic mapped kernel (0)
 	int candidate_capacity = 0;    // blob list: candidate slots per frame; 0 = max(4 * max_matches, 4096).  Overflow is handled exactly (rescan)
 	int sat_halo_strips = 1;       // vp_frame: resampling also writes the dense halo strips the tiled SAT pass reads (0: the pass reads its halo columns from flat)

@@ -599,6 +599,13 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			// The loop over the workgroup's frame groups sits BELOW the set-up (coordinate, footprints, box, weights, addresses: about a third of the kernel's VALU
 			// instructions at one group per workgroup), which is paid once for all of them.
 			auto run_fp = [&]() {
+				// frames whose boxes are in flight at a time (one register per lane each): 16 -> 80 VGPRs, six wavefronts per SIMD; 8 -> 72, seven.  Measured per
+				// 256-frame launch (profiles/r05_resample_lds_bound.json): 16 x 2 groups 1311 us, 8 x 4 sub-groups 1292, 8 x 8 1271, 4 x 16 1284
+#ifndef VP_RS_FPS
+#define VP_RS_FPS 8
+#endif
+				constexpr int FPS = VP_RS_FPS;
+				static_assert(RESAMPLE_FPT % FPS == 0 && FPS % 2 == 0, "sub-groups of whole frame pairs");
 				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: (2 wdw + 4) cells x (frame f, frame f + 1) | plane B likewise]
 				const int PL = 4 * wdw + 8, RP = 2 * PL;            // floats per plane of a box row, per box row
 				const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
@@ -670,10 +677,11 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				auto park_row = [&](int j, uint32_t px4) { // frame j: buffer (j >> 1) & 1, half j & 1 (asm: hipcc neither counts the LDS store -- the s_waitcnt before the step's barrier covers it -- nor pads the hazard: an SALU write of M0 needs one wait state before an LDS add-TID instruction)
 					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(px4), "s"(__builtin_amdgcn_readfirstlane((int)(row_m0 + (uint32_t)(((j >> 1) & 1) * 2 + (j & 1)) * 1024u))) : "m0", "memory");
 				};
-				for(int gi = 0; gi < groups_per_wg; gi++) {
-					const int g0 = f0 + gi * RESAMPLE_FPT; // this group's first frame
+				// (sub-groups of FPS frames: the boxes of FPS frames are in flight at a time -- FPS registers per lane)
+				for(int gi = 0; gi < groups_per_wg * (RESAMPLE_FPT / FPS); gi++) {
+					const int g0 = f0 + gi * FPS; // this sub-group's first frame
 					if(g0 >= batch) break;
-					const int nfg = min(batch - g0, RESAMPLE_FPT);
+					const int nfg = min(batch - g0, FPS);
 					// this group's buffer windows (32-bit lane offsets + a per-frame scalar offset; the spans were checked for a full group)
 					const __amdgpu_buffer_rsrc_t grs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)g0 * src_frame_bytes, 0, (int)((size_t)nfg * src_frame_bytes), 0x00020000);
 					const __amdgpu_buffer_rsrc_t grs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)g0 * npx * 4, 0, (int)((size_t)nfg * npx * 4), 0x00020000);
@@ -686,14 +694,14 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					};
 					// the boxes of all the group's frames are requested up front (no store of THIS group is in flight yet; what is left of the previous group's
 					// stores is drained by the first wait below: once per group, not per frame)
-					uint32_t pre[RESAMPLE_FPT];
+					uint32_t pre[FPS];
 #pragma unroll
-					for(int j = 0; j < RESAMPLE_FPT; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(grs_raw, goff, (uint32_t)min(j, nfg - 1) * fb_raw, 0);
+					for(int j = 0; j < FPS; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(grs_raw, goff, (uint32_t)min(j, nfg - 1) * fb_raw, 0);
 					if(gi) __syncthreads(); // the previous group's last stage reads are done before this group's first frames are parked
 					put(0, pre[0], pre[1]);
 					__syncthreads();
 #pragma unroll
-					for(int jj = 0; jj < RESAMPLE_FPT / 2; jj++) {
+					for(int jj = 0; jj < FPS / 2; jj++) {
 						const int j = 2 * jj;
 						if(j >= nfg) break;
 						const int o = (jj & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
 						const uint32_t a3 = (uint32_t)t3.x, b3 = (uint32_t)t3.y;
 						__builtin_amdgcn_sched_barrier(0); // (the staging below needs registers of its own: only once the products are dead)
-						if(j + 2 < nfg) put((jj + 1) & 1, pre[j + 2 < RESAMPLE_FPT ? j + 2 : j], pre[j + 3 < RESAMPLE_FPT ? j + 3 : j + 1]);
+						if(j + 2 < nfg) put((jj + 1) & 1, pre[j + 2 < FPS ? j + 2 : j], pre[j + 3 < FPS ? j + 3 : j + 1]);
 						const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
 						const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
 						gstore(pxa, (uint32_t)j * fb_flat);
@@ -1033,8 +1041,9 @@ int vp_resample_raw_mapped_impl(VpContext* ctx, int stream, const uint8_t* raw, 
 		const bool flat_nt = (size_t)fw * fh * 4 * batch > (size_t(112) << 20); // see store_flat in k_resample_staged
 		// frame groups per workgroup: the set-up is paid once for all of them; only where enough workgroups remain to fill the chip several times over
 		const int n_groups = (int)vp_div_up(batch, RESAMPLE_FPT);
-		// (measured at 256 frames: 1 -> 1367, 2 -> 1305, 4 -> 1304, 8 -> 1308 us per launch; only the frame-pair body loops over groups)
-		const int gpw = variant != 3 ? 1 : std::min(ctx->tune.resample_groups_per_wg > 0 ? ctx->tune.resample_groups_per_wg : 2, n_groups);
+		// (measured at 256 frames with 16 frames in flight: 1 -> 1367, 2 -> 1305, 4 -> 1304, 8 -> 1308 us per launch; with 8 in flight: 2 -> 1292, 4 -> 1271;
+		// only the frame-pair body loops over groups)
+		const int gpw = variant != 3 ? 1 : std::min(ctx->tune.resample_groups_per_wg > 0 ? ctx->tune.resample_groups_per_wg : 4, n_groups);
 		const dim3 gridg(grid.x, grid.y, vp_div_up(n_groups, gpw));
 #define VP_RST(L, V) \
 		do { \
