@@ -186,6 +186,20 @@ def test_placement_search_keeps_to_its_cap_and_reports_an_exhausted_budget(env):
         ctx.tune("placement_candidates", 0)  # take what hipMalloc gives
         r = placed(1)[0]
         assert r["raw_selected"] == 0 and r["candidates"] == 1 and "warning" not in r, r
+        # frame slabs: ONE fast block (the table's) ends the search, but two blocks are handed out whenever it ends -- also when the very first candidate is fast
+        # (that case once returned a slab whose flat was NULL: bench.py under rocprofv3 --pmc tripped over it)
+        ctx.tune("placement_candidates", 96)
+        ctx.tune("placement_max_mib", -1)
+        cfg = cfgs.CFG2
+        p = capi.frame_params(cfg)
+        for _ in range(12):
+            slab = ctx.frame_slab(p, 64)  # 805 MB blocks: searched
+            try:
+                assert slab.b.flat and slab.b.sat and slab.b.flat != slab.b.sat, (slab.b.flat, slab.b.sat)
+                ps, pf = slab.placement["sat"], slab.placement["flat"]
+                assert ps["candidates"] >= 2 and ps["write_gbs"] >= pf["write_gbs"] > 1000 and ps["fast_gbs"] > 1000, slab.placement
+            finally:
+                slab.destroy()
         free1, _ = torch.cuda.mem_get_info()
         assert free1 >= free0 - (64 << 20), (free0, free1)  # every candidate went back
     finally:

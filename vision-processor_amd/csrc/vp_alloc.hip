@@ -141,7 +141,7 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 		cands.push_back({p, gbs});
 		if(select) {
 			n_fast += fast_gbs > 0.f && gbs >= fast_gbs;
-			if(n_fast >= (need_fast > 0 ? need_fast : count)) {
+			if(n_fast >= (need_fast > 0 ? need_fast : count) && (int)cands.size() >= count) { // (enough fast ones AND enough blocks to hand out)
 				met = true;
 				break;
 			}
@@ -157,6 +157,11 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 				}
 			}
 		}
+	}
+	if((int)cands.size() < count) { // (cannot happen: every exit above holds at least `count` blocks -- kept as a guard, a short list once handed out a null flat)
+		release_all();
+		vp_set_error("vp_malloc_device_placed: internal error, %d of %d blocks", (int)cands.size(), count);
+		return VP_ERR_NOMEM;
 	}
 	std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.gbs > b.gbs; });
 	for(int i = 0; i < count; i++) {
