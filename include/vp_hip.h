@@ -105,7 +105,7 @@ const char* vp_device_name(VpContext* ctx);
  *   "resample_bgr_staged" 0 / 1 (default 1), "candidate_capacity" n (0 = max(4 * max_matches, 4096); a frame with more candidates
  *   is rescanned, still exact), "tail_segment_rows" n (0 = automatic), "tail_emit_kernel" 0 / 1 (default 1: the walkers' survivors become records in a second
  *   launch, one workgroup per frame; 0: inside the walker), "sat_halo_strips" 0 / 1 (default 1: vp_frame lets the resampling kernel
- *   write the dense halo strips the tiled SAT pass reads), "placement_max_mib" n (default 0: MiB a placement search may hold at once, 0 = half of the free memory but at most a quarter of the device; -1 = the calling process owns the GPU: half of the free memory), "placement_candidates" 0..256 (default 96: blocks vp_malloc_device_placed may probe per
+ *   write the dense halo strips the tiled SAT pass reads), "placement_max_mib" n (default 0: MiB a placement search may hold at once, 0 = half of the free memory but at most a quarter of the device; -1 = the calling process owns the GPU: nine tenths of the free memory), "placement_candidates" 0..256 (default 96: blocks vp_malloc_device_placed may probe per
  *   request; 0 or 1 = take what hipMalloc gives), "frame_graph" 0 / 1 / 2 (default 0; 1: vp_frame captures the launches of a (stream, parameters, batch,
  *   buffers) call into a hipGraph when the call follows itself on the stream and replays the graph from then on; a stream whose state belongs to another
  *   tuple -- another launch shape, another geometry -- takes the ordinary path, which repairs it; calls with stage events enabled or debug views always
@@ -143,7 +143,7 @@ int vp_probe_stream(VpContext* ctx, int stream, void* ptr, size_t bytes, int wri
  * sixteen candidates lie within 6 % of each other; it never holds more than half of the free device memory and a quarter of the device, or "placement_max_mib" MiB (vp_ctx_tune,
  * default 0 = that rule), and it asks the device before every candidate and stops while an eighth of the device is still free, so that a second context or
  * process on the GPU keeps room (its hipMalloc must not fail because this search is shopping).  A process that owns its GPU says so with
- * "placement_max_mib" = -1: half of the free memory, no reserve (bench.py, vp_feeds).  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
+ * "placement_max_mib" = -1: nine tenths of the free memory, no reserve (bench.py, vp_feeds).  Blocks below 768 MiB are plain hipMalloc (their writes live in the 256 MiB Infinity Cache).  Free with vp_free_device. */
 typedef struct {
 	float write_gbs;            /* zero-fill rate of this block, GB/s (0 when nothing was probed) */
 	float best_gbs, worst_gbs;  /* over the candidates probed for the request */
