@@ -148,6 +148,9 @@ void vp_frame_graphs_clear(VpContext* ctx); // vp_frame.hip
 // vp_alloc.hip
 int vp_probe_stream_impl(VpContext* ctx, int stream, void* ptr, size_t bytes, int write, int reps, float* us);
 
+#ifndef VP_STAGE_EVENT_FLAGS
+#define VP_STAGE_EVENT_FLAGS hipEventDisableSystemFence
+#endif
 // RAII bracket for per-stage hipEvent timing (the cl::Event list of opencl.h:84)
 struct VpStageTimer {
 	VpContext* ctx;
@@ -155,7 +158,9 @@ struct VpStageTimer {
 	const char* stage;
 	hipEvent_t start = nullptr, stop = nullptr;
 	VpStageTimer(VpContext* c, int stream, const char* name): ctx(c), s(c->streams[stream]), stage(name) {
-		if(ctx->events_on && hipEventCreate(&start) == hipSuccess && hipEventCreate(&stop) == hipSuccess) (void)hipEventRecord(start, s);
+		// (timing-only events: no system-scope fence when they fire -- the default writes the caches back and invalidates them at every stage boundary, which
+		// the NEXT kernel pays for)
+		if(ctx->events_on && hipEventCreateWithFlags(&start, VP_STAGE_EVENT_FLAGS) == hipSuccess && hipEventCreateWithFlags(&stop, VP_STAGE_EVENT_FLAGS) == hipSuccess) (void)hipEventRecord(start, s);
 	}
 	~VpStageTimer() {
 		if(start && stop) {
