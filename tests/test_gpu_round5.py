@@ -209,7 +209,8 @@ def test_placement_search_keeps_to_its_cap_and_reports_an_exhausted_budget(env):
 @pytest.mark.parametrize("shift", [0.0, -0.45, 0.45], ids=["centred", "past_the_left_border", "past_the_right_border"])
 def test_resampling_frame_pairs_and_groups_per_workgroup(env, port, shift):
     """k_resample_staged<., 3> (the default): the footprint box staged as floats of two frames side by side, both frames computed at once, a workgroup
-    taking several 16-frame groups with one set-up.  37 frames = groups of 16 + 16 + 5 (an odd last group: a half-filled last pair), every
+    taking several 16-frame groups with one set-up.  101 frames = 64 (one workgroup's full share: the written-out stream) + groups of 16 + 16 + 5 (an odd
+    last group: a half-filled last pair), every
     "resample_groups_per_wg" setting and the older stage formats must give the same flat images, and frames on both sides of every group boundary must be
     the oracle's.  `shift` moves the field window so that the left / right part of flat looks past the sensor border: there a footprint's two columns
     clamp onto one cell (resampling.cl:50 with CLK_ADDRESS_CLAMP_TO_EDGE), which the frame-pair body reads from a copy of the border cell in a virtual
@@ -217,12 +218,13 @@ def test_resampling_frame_pairs_and_groups_per_workgroup(env, port, shift):
     capi, torch = env
     base = cfgs.T_MID
     cfg = base.with_(name=f"{base.name}_shift{shift}", off_x=base.off_x + shift * base.fw * base.field_scale) if shift else base
-    B, mm = 37, cfg.max_matches
+    # 101 frames: with the default four groups per workgroup the first 64 take the written-out, software-prefetched pair stream, the other 37 the loop
+    B, mm = 101, cfg.max_matches
     raws = np.stack([cfg.synth(6200 + i) for i in range(B)])
     d_raw = torch.from_numpy(raws).cuda()
     model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
     want = {}
-    for k in (0, 15, 16, 31, 32, 35, 36):
+    for k in (0, 1, 3, 4, 15, 16, 31, 32, 62, 63, 64, 79, 80, 95, 96, 99, 100):
         s = port.frame_scratch(cfg.qw, cfg.qh, cfg.fw, cfg.fh, mm)
         port.frame(raws[k], cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
                    cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm, scratch=s)

@@ -8,6 +8,7 @@
 // rounded fp32 division.  Integer-linear sampling follows VpSamplerMode (frozen in oracle/ref_shim.c).
 #include "vp_common.h"
 #include <type_traits>
+#include <utility>
 #include <algorithm>
 
 // ---------------------------------------------------------------- raw2quad ----------------------------------------
@@ -261,6 +262,9 @@ __device__ __forceinline__ uint32_t drgb_pack7(uint32_t r, uint32_t g, uint32_t 
 	return __builtin_amdgcn_perm(z, xy, 0x0d050100u);             // [x.b1, y.b1, z.b1, 0xFF]
 }
 typedef float vp_f2 __attribute__((ext_vector_type(2)));
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), written out
+template<class F, int... I> __device__ __forceinline__ void vp_unroll_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
+template<int N, class F> __device__ __forceinline__ void vp_unroll(F& f) { vp_unroll_impl(f, std::make_integer_sequence<int, N>()); }
 typedef float vp_f4 __attribute__((ext_vector_type(4)));
 
 // Staged variant of the Bayer footprint: all texels of one sensor row that a flat pixel needs (two even-column and two
@@ -602,7 +606,13 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				// frames whose boxes are in flight at a time (one register per lane each): 16 -> 80 VGPRs, six wavefronts per SIMD; 8 -> 72, seven.  Measured per
 				// 256-frame launch (profiles/r05_resample_lds_bound.json): 16 x 2 groups 1311 us, 8 x 4 sub-groups 1292, 8 x 8 1271, 4 x 16 1284
 #ifndef VP_RS_FPS
-#define VP_RS_FPS 8
+#define VP_RS_FPS 4
+#endif
+#ifndef VP_RS_NSETS
+#define VP_RS_NSETS 2
+#endif
+#ifndef VP_RS_NSUB
+#define VP_RS_NSUB 16 // sub-groups of the written-out (FULL) path: groups_per_wg x RESAMPLE_FPT / FPS must equal it (4 groups of 16 frames)
 #endif
 				constexpr int FPS = VP_RS_FPS;
 				static_assert(RESAMPLE_FPT % FPS == 0 && FPS % 2 == 0, "sub-groups of whole frame pairs");
@@ -677,13 +687,25 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				auto park_row = [&](int j, uint32_t px4) { // frame j: buffer (j >> 1) & 1, half j & 1 (asm: hipcc neither counts the LDS store -- the s_waitcnt before the step's barrier covers it -- nor pads the hazard: an SALU write of M0 needs one wait state before an LDS add-TID instruction)
 					asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(px4), "s"(__builtin_amdgcn_readfirstlane((int)(row_m0 + (uint32_t)(((j >> 1) & 1) * 2 + (j & 1)) * 1024u))) : "m0", "memory");
 				};
-				// (sub-groups of FPS frames: the boxes of FPS frames are in flight at a time -- FPS registers per lane)
-				for(int gi = 0; gi < groups_per_wg * (RESAMPLE_FPT / FPS); gi++) {
-					const int g0 = f0 + gi * FPS; // this sub-group's first frame
-					if(g0 >= batch) break;
-					const int nfg = min(batch - g0, FPS);
-					// this group's buffer windows (32-bit lane offsets + a per-frame scalar offset; the spans were checked for a full group)
+				// Sub-groups of FPS frames.  Vector memory operations of a wavefront retire in order: a load issued behind stores waits for them to be written out,
+				// a load issued ahead of them returns as soon as its data is there.  So the boxes of sub-group k + 1 are requested at the START of sub-group k,
+				// before any of k's stores -- taking the sensor loads off the critical path is worth 19 % of the kernel (ablation: 1272 -> 1027 us per 256 frames
+				// when only the first sub-group loads at all).  hipcc sets the partial vmcnt waits this needs only in straight-line code (at a loop's back edge it
+				// merges the wait-count state and waits for everything: 7 % SLOWER, profiles/r05_resample_lds_bound.json), hence: a workgroup whose sub-groups are
+				// all complete runs them written out one after the other (FULL), two register sets of FPS dwords taking turns; anything else takes the loop.
+				const int nsub = groups_per_wg * (RESAMPLE_FPT / FPS);
+				auto request = [&](int gi, uint32_t (&pre)[FPS], int nfg) { // one dword per lane and frame of sub-group gi
+					const int g0 = f0 + gi * FPS;
 					const __amdgpu_buffer_rsrc_t grs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)g0 * src_frame_bytes, 0, (int)((size_t)nfg * src_frame_bytes), 0x00020000);
+#pragma unroll
+					for(int j = 0; j < FPS; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(grs_raw, goff, (uint32_t)min(j, nfg - 1) * fb_raw, 0);
+				};
+				// one sub-group: FULLT = std::true_type -> FPS frames, no run-time tests; `first`: no barrier needed before the first frames are parked
+				auto subgroup = [&](auto fullt, int gi, uint32_t (&pre)[FPS], int nfg_rt, bool first) {
+					constexpr bool FULL = decltype(fullt)::value;
+					const int g0 = f0 + gi * FPS; // this sub-group's first frame
+					const int nfg = FULL ? FPS : nfg_rt;
+					// this sub-group's buffer windows (32-bit lane offsets + a per-frame scalar offset; the spans were checked for a full group)
 					const __amdgpu_buffer_rsrc_t grs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)g0 * npx * 4, 0, (int)((size_t)nfg * npx * 4), 0x00020000);
 					const __amdgpu_buffer_rsrc_t grs_strip = __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)g0 * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
 							(int)((size_t)nfg * strips.frame_words * 4), 0x00020000);
@@ -692,20 +714,16 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						if(agg && wave == (j & 3) && rec_lane)
 							__builtin_amdgcn_raw_buffer_store_b32(rec_src[(((j >> 1) & 1) * 2 + (j & 1)) * 256], grs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
 					};
-					// the boxes of all the group's frames are requested up front (no store of THIS group is in flight yet; what is left of the previous group's
-					// stores is drained by the first wait below: once per group, not per frame)
-					uint32_t pre[FPS];
-#pragma unroll
-					for(int j = 0; j < FPS; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(grs_raw, goff, (uint32_t)min(j, nfg - 1) * fb_raw, 0);
-					if(gi) __syncthreads(); // the previous group's last stage reads are done before this group's first frames are parked
+					(void)first; // (no barrier before the first frames are parked: the previous sub-group's last pair ended with one, and it read the OTHER buffer's
+					             // successor -- buffer 0 was last read one barrier earlier)
 					put(0, pre[0], pre[1]);
 					__syncthreads();
 #pragma unroll
 					for(int jj = 0; jj < FPS / 2; jj++) {
 						const int j = 2 * jj;
-						if(j >= nfg) break;
+						if(!FULL && j >= nfg) break;
 						const int o = (jj & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
-						// (two channels' texels in flight at a time: all sixteen 8-byte reads up front cost 24 more VGPRs)
+						// (one channel's texels in flight at a time: all sixteen 8-byte reads up front cost 24 more VGPRs)
 						const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
 						const uint32_t a0 = (uint32_t)t0.x, b0 = (uint32_t)t0.y; // a: frame j, b: frame j + 1; the greens halved
 						__builtin_amdgcn_sched_barrier(0);
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
 						const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
 						gstore(pxa, (uint32_t)j * fb_flat);
-						if(j + 1 < nfg) gstore(pxb, (uint32_t)(j + 1) * fb_flat);
+						if(FULL || j + 1 < nfg) gstore(pxb, (uint32_t)(j + 1) * fb_flat);
 						if(agg) {
 							park_row(j, pxa);
 							park_row(j + 1, pxb);
@@ -737,6 +755,78 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					const int last = (nfg - 1) & ~1; // the last pair's records
 					flush(last);
 					if(last + 1 < nfg) flush(last + 1);
+				};
+				uint32_t pre_a[FPS], pre_b[FPS];
+				if(nsub == VP_RS_NSUB && f0 + nsub * FPS <= batch) {
+					// FULL: VP_RS_NSUB complete sub-groups as ONE written-out stream of frame pairs.  Pair p = frames 2p, 2p + 1 of the workgroup; stage buffer p & 1;
+					// sub-group p / (FPS / 2) holds its dwords in register set (p / (FPS / 2)) & 1; the first pair of a sub-group requests the NEXT sub-group's
+					// boxes before it stores anything; every pair parks the next pair's texels (from whichever set holds them) and ends with the one barrier.
+					constexpr int PPS = FPS / 2, NP = VP_RS_NSUB * PPS; // pairs per sub-group, pairs in all
+					static_assert(VP_RS_NSUB % 2 == 0 && NP <= 64, "sub-groups come in pairs");
+					constexpr int NSETS = VP_RS_NSETS; // register sets of FPS dwords: sub-group s lives in set s % NSETS and is requested NSETS - 1 sub-groups ahead
+					uint32_t pre[NSETS][FPS];
+					auto dw = [&](int pp, int k) -> uint32_t { // dword k (0 / 1) of pair pp: sub-group pp / PPS, frame 2 (pp % PPS) + k of it
+						return pre[(pp / PPS) % NSETS][2 * (pp % PPS) + k];
+					};
+					auto flat_rs = [&](int pp) { return __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)(f0 + 2 * pp) * npx * 4, 0, (int)(2 * npx * 4), 0x00020000); };
+					auto strip_rs = [&](int pp) {
+						return __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)(f0 + 2 * pp) * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
+								(int)(2 * strips.frame_words * 4), 0x00020000);
+					};
+					auto flush_pair = [&](int pp) { // the two strip records of pair pp, by wavefronts (2 pp) % 4 and (2 pp + 1) % 4
+						if(agg && rec_lane) {
+							const __amdgpu_buffer_rsrc_t rs = strip_rs(pp);
+							if(wave == ((2 * pp) & 3)) __builtin_amdgcn_raw_buffer_store_b32(rec_src[((pp & 1) * 2 + 0) * 256], rs, voff_rec, 0u, 0);
+							if(wave == ((2 * pp + 1) & 3)) __builtin_amdgcn_raw_buffer_store_b32(rec_src[((pp & 1) * 2 + 1) * 256], rs, voff_rec, fb_strip, 0);
+						}
+					};
+#pragma unroll
+					for(int sg = 0; sg < NSETS - 1 && sg < VP_RS_NSUB; sg++) request(sg, pre[sg], FPS);
+					put(0, pre[0][0], pre[0][1]);
+					__syncthreads();
+					auto pair_step = [&](auto pc) {
+						constexpr int pp = decltype(pc)::value;
+						if(pp % PPS == 0 && pp / PPS + NSETS - 1 < VP_RS_NSUB) { // first pair of a sub-group: request the boxes of the sub-group NSETS - 1 ahead, before this one's stores
+							request(pp / PPS + NSETS - 1, pre[(pp / PPS + NSETS - 1) % NSETS], FPS);
+							__builtin_amdgcn_sched_barrier(0); // (the requests stay where they are written)
+						}
+						constexpr int o = (pp & 1) * 1024;
+						const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
+						const uint32_t a0 = (uint32_t)t0.x, b0 = (uint32_t)t0.y; // a: frame 2 pp, b: frame 2 pp + 1; the greens halved
+						__builtin_amdgcn_sched_barrier(0);
+						const vp_f2 t1 = sum2(w1a, w1b, q10, q11, o);
+						const uint32_t a1 = (uint32_t)t1.x, b1 = (uint32_t)t1.y;
+						__builtin_amdgcn_sched_barrier(0);
+						const vp_f2 t2 = sum2(w2a, w2b, q20, q21, o);
+						const uint32_t a2 = (uint32_t)t2.x, b2 = (uint32_t)t2.y;
+						__builtin_amdgcn_sched_barrier(0);
+						const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
+						const uint32_t a3 = (uint32_t)t3.x, b3 = (uint32_t)t3.y;
+						__builtin_amdgcn_sched_barrier(0);
+						if(pp + 1 < NP) put((pp + 1) & 1, dw(pp + 1, 0), dw(pp + 1, 1));
+						const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
+						const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
+						const __amdgpu_buffer_rsrc_t rs = flat_rs(pp);
+						__builtin_amdgcn_raw_buffer_store_b32(pxa, rs, voff_out, 0u, NTS ? 2 : 0);
+						__builtin_amdgcn_raw_buffer_store_b32(pxb, rs, voff_out, fb_flat, NTS ? 2 : 0);
+						if(agg) {
+							park_row(2 * pp, pxa);
+							park_row(2 * pp + 1, pxb);
+						}
+						if(pp > 0) flush_pair(pp - 1);
+						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						__syncthreads();
+					};
+					vp_unroll<NP>(pair_step);
+					flush_pair(NP - 1);
+				} else {
+					for(int gi = 0; gi < nsub; gi++) {
+						const int g0 = f0 + gi * FPS;
+						if(g0 >= batch) break;
+						const int nfg = min(batch - g0, FPS);
+						request(gi, pre_a, nfg); // (what is left of the previous sub-group's stores is drained by the first wait: once per sub-group)
+						subgroup(std::false_type(), gi, pre_a, nfg, gi == 0);
+					}
 				}
 			};
 			// NEAREST: the boxes of all frames up front (as `run`), then four byte picks per pixel and frame
