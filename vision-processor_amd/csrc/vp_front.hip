@@ -757,10 +757,14 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					if(last + 1 < nfg) flush(last + 1);
 				};
 				uint32_t pre_a[FPS], pre_b[FPS];
-				if(nsub == VP_RS_NSUB && f0 + nsub * FPS <= batch) {
-					// FULL: VP_RS_NSUB complete sub-groups as ONE written-out stream of frame pairs.  Pair p = frames 2p, 2p + 1 of the workgroup; stage buffer p & 1;
-					// sub-group p / (FPS / 2) holds its dwords in register set (p / (FPS / 2)) & 1; the first pair of a sub-group requests the NEXT sub-group's
-					// boxes before it stores anything; every pair parks the next pair's texels (from whichever set holds them) and ends with the one barrier.
+				const int fr_wg = min(batch - f0, nsub * FPS), nsub_full = fr_wg / FPS; // this workgroup's frames; its complete sub-groups
+				if(nsub <= VP_RS_NSUB && nsub_full > 0) {
+					// The workgroup's complete sub-groups (up to VP_RS_NSUB) as ONE written-out stream of frame pairs.  Pair p = frames 2p, 2p + 1 of the workgroup;
+					// stage buffer p & 1; sub-group p / (FPS / 2) holds its dwords in register set (p / (FPS / 2)) % NSETS; the first pair of a sub-group requests a
+					// later sub-group's boxes before it stores anything (past the workgroup's last complete sub-group: that one again, harmless); every pair parks
+					// the next pair's texels (from whichever set holds them) and ends with the one barrier.  The stream is LEFT, never skipped over, at the first
+					// sub-group the workgroup does not have (a forward exit: no wait-count state is merged on the path that goes on); a last incomplete sub-group
+					// takes the loop body below.
 					constexpr int PPS = FPS / 2, NP = VP_RS_NSUB * PPS; // pairs per sub-group, pairs in all
 					static_assert(VP_RS_NSUB % 2 == 0 && NP <= 64, "sub-groups come in pairs");
 					constexpr int NSETS = VP_RS_NSETS; // register sets of FPS dwords: sub-group s lives in set s % NSETS and is requested NSETS - 1 sub-groups ahead
@@ -781,13 +785,13 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						}
 					};
 #pragma unroll
-					for(int sg = 0; sg < NSETS - 1 && sg < VP_RS_NSUB; sg++) request(sg, pre[sg], FPS);
+					for(int sg = 0; sg < NSETS - 1 && sg < VP_RS_NSUB; sg++) request(min(sg, nsub_full - 1), pre[sg], FPS);
 					put(0, pre[0][0], pre[0][1]);
 					__syncthreads();
 					auto pair_step = [&](auto pc) {
 						constexpr int pp = decltype(pc)::value;
 						if(pp % PPS == 0 && pp / PPS + NSETS - 1 < VP_RS_NSUB) { // first pair of a sub-group: request the boxes of the sub-group NSETS - 1 ahead, before this one's stores
-							request(pp / PPS + NSETS - 1, pre[(pp / PPS + NSETS - 1) % NSETS], FPS);
+							request(min(pp / PPS + NSETS - 1, nsub_full - 1), pre[(pp / PPS + NSETS - 1) % NSETS], FPS);
 							__builtin_amdgcn_sched_barrier(0); // (the requests stay where they are written)
 						}
 						constexpr int o = (pp & 1) * 1024;
@@ -817,8 +821,24 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 						__syncthreads();
 					};
-					vp_unroll<NP>(pair_step);
-					flush_pair(NP - 1);
+					auto run_from = [&](auto self, auto pc) -> void { // pair pp and everything after it
+						constexpr int pp = decltype(pc)::value;
+						if constexpr(pp < NP) {
+							if constexpr(pp % PPS == 0 && pp > 0) {
+								if(pp / PPS >= nsub_full) { // the workgroup has no such sub-group: leave
+									flush_pair(pp - 1);
+									return;
+								}
+							}
+							pair_step(pc);
+							self(self, std::integral_constant<int, pp + 1>());
+						} else flush_pair(NP - 1);
+					};
+					run_from(run_from, std::integral_constant<int, 0>());
+					if(fr_wg % FPS) { // a last incomplete sub-group
+						request(nsub_full, pre_a, fr_wg % FPS);
+						subgroup(std::false_type(), nsub_full, pre_a, fr_wg % FPS, false);
+					}
 				} else {
 					for(int gi = 0; gi < nsub; gi++) {
 						const int g0 = f0 + gi * FPS;
