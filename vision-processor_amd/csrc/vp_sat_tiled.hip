@@ -477,7 +477,11 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	const uint32_t out_voff = ((uint32_t)(16 * wv + 4 * q) * (uint32_t)w + 4u * (uint32_t)m) * 4u;
 
 	for(;;) {
-		const uint32_t tcur = a.order[__builtin_amdgcn_readfirstlane(rem)];
+		// (the tile-order table is written by the host before the launch and only read here: a SCALAR load.  As a vector load at the top of the tile loop it made
+		// the wavefront wait for vmcnt(0) -- for the previous tile's stores to retire -- before it could commit the prefetched tile; now the wait is vmcnt(4):
+		// - 0.4 % per 256-frame launch, - 3 % per 8-frame and single-frame launch)
+		typedef __attribute__((address_space(4))) const uint32_t c_u32;
+		const uint32_t tcur = ((c_u32*)a.order)[__builtin_amdgcn_readfirstlane(rem)];
 		const int ti = (int)(tcur >> 16), tj = (int)(tcur & 0xFFFF);
 		const int x0 = tj * TW, y0 = ti * TH;
 
