@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 		int qw, int qh, int fw, int fh, size_t src_frame_bytes, const VpStrips strips, int batch, int xcd_map, int groups_per_wg) {
 	__shared__ __attribute__((aligned(16))) uint32_t stage[RESAMPLE_FPT][STAGE_DW];
 	__shared__ __attribute__((aligned(16))) uint32_t fp_rows[2][2][4][64]; // run_fp: the workgroup's 4 x 64 flat pixels of the two frames of a step (the strip records are gathered from them), double buffered
-	__shared__ uint32_t red[4][2];
+	uint32_t (*red)[2] = reinterpret_cast<uint32_t (*)[2]>(&fp_rows[0][0][0][0]); // the set-up's box reduction (done with before anything is parked): 20 480 B of LDS per workgroup, eight per CU
 	const unsigned bz = blockIdx.z;
 	// Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  A workgroup's box shares its 64/128-byte lines with the
 	// boxes left and right of it and two to four sensor rows with those above and below; with the plain mapping horizontal
@@ -457,8 +457,9 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			red[threadIdx.y][1] = hi_w;
 		}
 		__syncthreads();
-		const uint32_t lo = pk16_min(pk16_min(red[0][0], red[1][0]), pk16_min(red[2][0], red[3][0]));
-		const uint32_t hi = pk16_max(pk16_max(red[0][1], red[1][1]), pk16_max(red[2][1], red[3][1]));
+		// (workgroup-uniform, and said to be: everything derived from the box lives in SGPRs and branches on it are scalar)
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk16_min(pk16_min(red[0][0], red[1][0]), pk16_min(red[2][0], red[3][0])));
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk16_max(pk16_max(red[0][1], red[1][1]), pk16_max(red[2][1], red[3][1])));
 		const int cmin = (int)(lo & 0xFFFF), rmin = (int)(lo >> 16), cmax = (int)(hi & 0xFFFF), rmax = (int)(hi >> 16);
 		const int wdw = cmax - cmin, hr = rmax - rmin + 1, ndw = wdw * hr;
 		// The workgroup's first frame group (up to RESAMPLE_FPT frames [f0, f1)); run_fp goes on to the next groups_per_wg - 1 by itself.
@@ -603,8 +604,9 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 			// The loop over the workgroup's frame groups sits BELOW the set-up (coordinate, footprints, box, weights, addresses: about a third of the kernel's VALU
 			// instructions at one group per workgroup), which is paid once for all of them.
 			auto run_fp = [&]() {
-				// frames whose boxes are in flight at a time (one register per lane each): 16 -> 80 VGPRs, six wavefronts per SIMD; 8 -> 72, seven.  Measured per
-				// 256-frame launch (profiles/r05_resample_lds_bound.json): 16 x 2 groups 1311 us, 8 x 4 sub-groups 1292, 8 x 8 1271, 4 x 16 1284
+				// FPS frames per sub-group (their boxes are requested together: one register per lane and frame), NSETS register sets taking turns, NSUB sub-groups
+				// in the written-out stream (profiles/r05_resample_lds_bound.json has the sweep: 16 frames x 1 set in a loop 1311 us per 256-frame launch, 8 x 1: 1271,
+				// 4 x 2 sets written out: 1195)
 #ifndef VP_RS_FPS
 #define VP_RS_FPS 4
 #endif
@@ -623,21 +625,28 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				const uint32_t goff = (uint32_t)(rmin + orow) * rowb + 4u * (uint32_t)(cmin + ocol);
 				float* wa = F + orow * RP + 4 * ocol + 4; // real cells 2 ocol, 2 ocol + 1 of plane A (behind the two spare cells); plane B PL floats on
 				const bool pad_l = cmin == 0, pad_r = 2 * cmax == qw;                     // workgroup-uniform: the box touches the left / right sensor border
-				const bool own_l = tid < ndw && ocol == 0, own_r = tid < ndw && ocol == wdw - 1; // the threads that hold cell 0 / cell qw - 1 of a box row
+				const bool own_l = pad_l && tid < ndw && ocol == 0, own_r = pad_r && tid < ndw && ocol == wdw - 1; // the threads that hold cell 0 / cell qw - 1 of a box row at the border
+				const bool pad_any = pad_l || pad_r;
+				// ONE predicated region for the two 16-byte stores, and a scalar branch around the border copies (taken by every workgroup that does not touch the
+				// sensor's left / right border): the step's instruction stream is what a wavefront's time goes into (profiles/r05_resample_issue_stream.json)
 				auto put = [&](int buf, uint32_t v0, uint32_t v1) { // frames f (v0) and f + 1 (v1) of this thread's dword
 					float* w = wa + buf * 2048;
-					{ // plane A: even sensor columns (one plane at a time: four conversion results alive, not eight)
-						const float a0 = (float)(v0 & 0xFF), a1 = (float)(v1 & 0xFF), c0 = (float)((v0 >> 16) & 0xFF), c1 = (float)((v1 >> 16) & 0xFF);
-						if(tid < ndw) *reinterpret_cast<vp_f4*>(w) = vp_f4{a0, a1, c0, c1};
-						if(pad_l && own_l) *reinterpret_cast<vp_f2*>(w - 2) = vp_f2{a0, a1}; // virtual cell -1 := cell 0
-						if(pad_r && own_r) *reinterpret_cast<vp_f2*>(w + 4) = vp_f2{c0, c1}; // virtual cell qw := cell qw - 1
+					// plane A: even sensor columns, plane B: odd ones
+					const float a0 = (float)(v0 & 0xFF), a1 = (float)(v1 & 0xFF), c0 = (float)((v0 >> 16) & 0xFF), c1 = (float)((v1 >> 16) & 0xFF);
+					const float b0 = (float)((v0 >> 8) & 0xFF), b1 = (float)((v1 >> 8) & 0xFF), d0 = (float)(v0 >> 24), d1 = (float)(v1 >> 24);
+					if(tid < ndw) {
+						*reinterpret_cast<vp_f4*>(w) = vp_f4{a0, a1, c0, c1};
+						*reinterpret_cast<vp_f4*>(w + PL) = vp_f4{b0, b1, d0, d1};
 					}
-					__builtin_amdgcn_sched_barrier(0);
-					{ // plane B: odd sensor columns
-						const float b0 = (float)((v0 >> 8) & 0xFF), b1 = (float)((v1 >> 8) & 0xFF), d0 = (float)(v0 >> 24), d1 = (float)(v1 >> 24);
-						if(tid < ndw) *reinterpret_cast<vp_f4*>(w + PL) = vp_f4{b0, b1, d0, d1};
-						if(pad_l && own_l) *reinterpret_cast<vp_f2*>(w + PL - 2) = vp_f2{b0, b1};
-						if(pad_r && own_r) *reinterpret_cast<vp_f2*>(w + PL + 4) = vp_f2{d0, d1};
+					if(__builtin_expect(pad_any, 0)) {
+						if(own_l) { // virtual cell -1 := cell 0
+							*reinterpret_cast<vp_f2*>(w - 2) = vp_f2{a0, a1};
+							*reinterpret_cast<vp_f2*>(w + PL - 2) = vp_f2{b0, b1};
+						}
+						if(own_r) { // virtual cell qw := cell qw - 1
+							*reinterpret_cast<vp_f2*>(w + 4) = vp_f2{c0, c1};
+							*reinterpret_cast<vp_f2*>(w + PL + 4) = vp_f2{d0, d1};
+						}
 					}
 				};
 				// the first cell of a footprint in virtual coordinates: the clamped pair (0, 0) is (-1, 0), the clamped pair (qw - 1, qw - 1) is (qw - 1, qw)
@@ -660,7 +669,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 				const vp_f2 w2a = vp_f2{(oxa * oyb) * h2, (g.xa * oyb) * h2}, w2b = vp_f2{(oxa * g.yb) * h2, (g.xa * g.yb) * h2};
 				const vp_f2 w3a = vp_f2{(oxb * oyb) * h3, (g.xb * oyb) * h3}, w3b = vp_f2{(oxb * g.yb) * h3, (g.xb * g.yb) * h3};
 				// (volatile: two 8-byte reads 8 bytes apart must NOT be merged into one ds_read2_b64 -- that costs 8 LDS cycles against 2 + 2, MI355X_MICROARCH.md, LDS)
-				auto sum2 = [&](vp_f2 wa_, vp_f2 wb_, const vp_f2* row0, const vp_f2* row1, int o) { // both frames: w00 t00 + w10 t10 + w01 t01 + w11 t11, in that order
+				auto sum2 = [&](vp_f2 wa_, vp_f2 wb_, const vp_f2* row0, const vp_f2* row1, int o, uint32_t& a, uint32_t& b) { // both frames (a, b): (uint)(w00 t00 + w10 t10 + w01 t01 + w11 t11), in that order
 					typedef __attribute__((address_space(3))) const volatile vp_f2 lds_f2;
 					lds_f2* v0 = (lds_f2*)(row0 + o);
 					lds_f2* v1 = (lds_f2*)(row1 + o);
@@ -675,7 +684,11 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					vp_f2 t = m00 + m10;
 					t = t + m01;
 					t = t + m11;
-					return t;
+					a = (uint32_t)t.x;
+					b = (uint32_t)t.y;
+					// finished HERE: left alone, the additions sink below the staging that follows the four channels and keep all 32 product registers alive through it
+					// (76 instead of 60 VGPRs; at <= 64 there are eight wavefronts per SIMD)
+					asm volatile("" : "+v"(a), "+v"(b));
 				};
 				// halo strips: every wavefront parks its 64 pixels of both frames (ds_write_addtid_b32), one wavefront per frame stores that frame's record a step later
 				const bool agg = strips.base != nullptr;
@@ -700,11 +713,9 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 #pragma unroll
 					for(int j = 0; j < FPS; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(grs_raw, goff, (uint32_t)min(j, nfg - 1) * fb_raw, 0);
 				};
-				// one sub-group: FULLT = std::true_type -> FPS frames, no run-time tests; `first`: no barrier needed before the first frames are parked
-				auto subgroup = [&](auto fullt, int gi, uint32_t (&pre)[FPS], int nfg_rt, bool first) {
-					constexpr bool FULL = decltype(fullt)::value;
+				// one sub-group of nfg <= FPS frames, as a loop body (partial workgroups, group settings the written-out stream does not cover)
+				auto subgroup = [&](int gi, uint32_t (&pre)[FPS], int nfg) {
 					const int g0 = f0 + gi * FPS; // this sub-group's first frame
-					const int nfg = FULL ? FPS : nfg_rt;
 					// this sub-group's buffer windows (32-bit lane offsets + a per-frame scalar offset; the spans were checked for a full group)
 					const __amdgpu_buffer_rsrc_t grs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)g0 * npx * 4, 0, (int)((size_t)nfg * npx * 4), 0x00020000);
 					const __amdgpu_buffer_rsrc_t grs_strip = __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)g0 * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
@@ -714,33 +725,29 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						if(agg && wave == (j & 3) && rec_lane)
 							__builtin_amdgcn_raw_buffer_store_b32(rec_src[(((j >> 1) & 1) * 2 + (j & 1)) * 256], grs_strip, voff_rec, (uint32_t)j * fb_strip, 0);
 					};
-					(void)first; // (no barrier before the first frames are parked: the previous sub-group's last pair ended with one, and it read the OTHER buffer's
-					             // successor -- buffer 0 was last read one barrier earlier)
+					// (no barrier before the first frames are parked: whatever ran before ended with one, and buffer 0 was last read a barrier earlier still)
 					put(0, pre[0], pre[1]);
 					__syncthreads();
 #pragma unroll
 					for(int jj = 0; jj < FPS / 2; jj++) {
 						const int j = 2 * jj;
-						if(!FULL && j >= nfg) break;
+						if(j >= nfg) break;
 						const int o = (jj & 1) * 1024; // in vp_f2 units: the second buffer starts 2048 floats on
 						// (one channel's texels in flight at a time: all sixteen 8-byte reads up front cost 24 more VGPRs)
-						const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
-						const uint32_t a0 = (uint32_t)t0.x, b0 = (uint32_t)t0.y; // a: frame j, b: frame j + 1; the greens halved
+						uint32_t a0, b0, a1, b1, a2, b2, a3, b3; // a: frame j, b: frame j + 1; the greens halved
+						sum2(w0a, w0b, q00, q01, o, a0, b0);
 						__builtin_amdgcn_sched_barrier(0);
-						const vp_f2 t1 = sum2(w1a, w1b, q10, q11, o);
-						const uint32_t a1 = (uint32_t)t1.x, b1 = (uint32_t)t1.y;
+						sum2(w1a, w1b, q10, q11, o, a1, b1);
 						__builtin_amdgcn_sched_barrier(0);
-						const vp_f2 t2 = sum2(w2a, w2b, q20, q21, o);
-						const uint32_t a2 = (uint32_t)t2.x, b2 = (uint32_t)t2.y;
+						sum2(w2a, w2b, q20, q21, o, a2, b2);
 						__builtin_amdgcn_sched_barrier(0);
-						const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
-						const uint32_t a3 = (uint32_t)t3.x, b3 = (uint32_t)t3.y;
+						sum2(w3a, w3b, q30, q31, o, a3, b3);
 						__builtin_amdgcn_sched_barrier(0); // (the staging below needs registers of its own: only once the products are dead)
 						if(j + 2 < nfg) put((jj + 1) & 1, pre[j + 2 < FPS ? j + 2 : j], pre[j + 3 < FPS ? j + 3 : j + 1]);
 						const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
 						const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
 						gstore(pxa, (uint32_t)j * fb_flat);
-						if(FULL || j + 1 < nfg) gstore(pxb, (uint32_t)(j + 1) * fb_flat);
+						if(j + 1 < nfg) gstore(pxb, (uint32_t)(j + 1) * fb_flat);
 						if(agg) {
 							park_row(j, pxa);
 							park_row(j + 1, pxb);
@@ -756,9 +763,9 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					flush(last);
 					if(last + 1 < nfg) flush(last + 1);
 				};
-				uint32_t pre_a[FPS], pre_b[FPS];
+				uint32_t pre_a[FPS];
 				const int fr_wg = min(batch - f0, nsub * FPS), nsub_full = fr_wg / FPS; // this workgroup's frames; its complete sub-groups
-				if(nsub <= VP_RS_NSUB && nsub_full > 0) {
+				if(nsub <= VP_RS_NSUB && nsub_full > 0 && (uint64_t)fr_wg * fb_flat <= 0xffffffffull && (uint64_t)fr_wg * fb_raw <= 0xffffffffull && (uint64_t)fr_wg * fb_strip <= 0xffffffffull) {
 					// The workgroup's complete sub-groups (up to VP_RS_NSUB) as ONE written-out stream of frame pairs.  Pair p = frames 2p, 2p + 1 of the workgroup;
 					// stage buffer p & 1; sub-group p / (FPS / 2) holds its dwords in register set (p / (FPS / 2)) % NSETS; the first pair of a sub-group requests a
 					// later sub-group's boxes before it stores anything (past the workgroup's last complete sub-group: that one again, harmless); every pair parks
@@ -772,47 +779,51 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					auto dw = [&](int pp, int k) -> uint32_t { // dword k (0 / 1) of pair pp: sub-group pp / PPS, frame 2 (pp % PPS) + k of it
 						return pre[(pp / PPS) % NSETS][2 * (pp % PPS) + k];
 					};
-					auto flat_rs = [&](int pp) { return __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)(f0 + 2 * pp) * npx * 4, 0, (int)(2 * npx * 4), 0x00020000); };
-					auto strip_rs = [&](int pp) {
-						return __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)(f0 + 2 * pp) * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
-								(int)(2 * strips.frame_words * 4), 0x00020000);
+					// ONE descriptor per buffer for the workgroup's frames, a frame = a scalar offset (the host-side condition below keeps every offset inside 32 bits);
+					// a descriptor per pair cost a 64-bit multiply-add in SALU instructions per pair and buffer
+					const __amdgpu_buffer_rsrc_t wrs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)f0 * npx * 4, 0, (int)((uint32_t)fr_wg * fb_flat), 0x00020000);
+					const __amdgpu_buffer_rsrc_t wrs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)f0 * src_frame_bytes, 0, (int)((uint32_t)fr_wg * fb_raw), 0x00020000);
+					const __amdgpu_buffer_rsrc_t wrs_strip = __builtin_amdgcn_make_buffer_rsrc(strips.base ? strips.base + (size_t)f0 * strips.frame_words : reinterpret_cast<uint32_t*>(flat), 0,
+							(int)((uint32_t)fr_wg * fb_strip), 0x00020000);
+					auto request_s = [&](int sg_rt, uint32_t (&pre)[FPS]) { // the boxes of sub-group sg_rt (< nsub_full)
+						const uint32_t so0 = (uint32_t)(sg_rt * FPS) * fb_raw;
+#pragma unroll
+						for(int j = 0; j < FPS; j++) pre[j] = __builtin_amdgcn_raw_buffer_load_b32(wrs_raw, goff, so0 + (uint32_t)j * fb_raw, 0);
 					};
-					auto flush_pair = [&](int pp) { // the two strip records of pair pp, by wavefronts (2 pp) % 4 and (2 pp + 1) % 4
-						if(agg && rec_lane) {
-							const __amdgpu_buffer_rsrc_t rs = strip_rs(pp);
-							if(wave == ((2 * pp) & 3)) __builtin_amdgcn_raw_buffer_store_b32(rec_src[((pp & 1) * 2 + 0) * 256], rs, voff_rec, 0u, 0);
-							if(wave == ((2 * pp + 1) & 3)) __builtin_amdgcn_raw_buffer_store_b32(rec_src[((pp & 1) * 2 + 1) * 256], rs, voff_rec, fb_strip, 0);
-						}
+					// The two strip records of pair pp: by wavefronts 0 and 1 (even pairs) / 2 and 3 (odd pairs), one frame each -- one predicated region, the
+					// wavefront's part (which half of the parked pair, which frame) in scalars set up once
+					const bool flush_even = agg && rec_lane && wave < 2, flush_odd = agg && rec_lane && wave >= 2;
+					const uint32_t* rec_src_w = rec_src + (wave & 1) * 256; // the wavefront's frame of a parked pair
+					const uint32_t rec_soff_w = (uint32_t)(wave & 1) * fb_strip;
+					auto flush_pair = [&](int pp) {
+						if(pp & 1 ? flush_odd : flush_even)
+							__builtin_amdgcn_raw_buffer_store_b32(rec_src_w[(pp & 1) * 512], wrs_strip, voff_rec, (uint32_t)(2 * pp) * fb_strip + rec_soff_w, 0);
 					};
 #pragma unroll
-					for(int sg = 0; sg < NSETS - 1 && sg < VP_RS_NSUB; sg++) request(min(sg, nsub_full - 1), pre[sg], FPS);
+					for(int sg = 0; sg < NSETS - 1 && sg < VP_RS_NSUB; sg++) request_s(min(sg, nsub_full - 1), pre[sg]);
 					put(0, pre[0][0], pre[0][1]);
 					__syncthreads();
 					auto pair_step = [&](auto pc) {
 						constexpr int pp = decltype(pc)::value;
 						if(pp % PPS == 0 && pp / PPS + NSETS - 1 < VP_RS_NSUB) { // first pair of a sub-group: request the boxes of the sub-group NSETS - 1 ahead, before this one's stores
-							request(min(pp / PPS + NSETS - 1, nsub_full - 1), pre[(pp / PPS + NSETS - 1) % NSETS], FPS);
+							request_s(min(pp / PPS + NSETS - 1, nsub_full - 1), pre[(pp / PPS + NSETS - 1) % NSETS]);
 							__builtin_amdgcn_sched_barrier(0); // (the requests stay where they are written)
 						}
 						constexpr int o = (pp & 1) * 1024;
-						const vp_f2 t0 = sum2(w0a, w0b, q00, q01, o);
-						const uint32_t a0 = (uint32_t)t0.x, b0 = (uint32_t)t0.y; // a: frame 2 pp, b: frame 2 pp + 1; the greens halved
+						uint32_t a0, b0, a1, b1, a2, b2, a3, b3; // a: frame 2 pp, b: frame 2 pp + 1; the greens halved
+						sum2(w0a, w0b, q00, q01, o, a0, b0);
 						__builtin_amdgcn_sched_barrier(0);
-						const vp_f2 t1 = sum2(w1a, w1b, q10, q11, o);
-						const uint32_t a1 = (uint32_t)t1.x, b1 = (uint32_t)t1.y;
+						sum2(w1a, w1b, q10, q11, o, a1, b1);
 						__builtin_amdgcn_sched_barrier(0);
-						const vp_f2 t2 = sum2(w2a, w2b, q20, q21, o);
-						const uint32_t a2 = (uint32_t)t2.x, b2 = (uint32_t)t2.y;
+						sum2(w2a, w2b, q20, q21, o, a2, b2);
 						__builtin_amdgcn_sched_barrier(0);
-						const vp_f2 t3 = sum2(w3a, w3b, q30, q31, o);
-						const uint32_t a3 = (uint32_t)t3.x, b3 = (uint32_t)t3.y;
+						sum2(w3a, w3b, q30, q31, o, a3, b3);
 						__builtin_amdgcn_sched_barrier(0);
 						if(pp + 1 < NP) put((pp + 1) & 1, dw(pp + 1, 0), dw(pp + 1, 1));
 						const uint32_t pxa = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(a0, a1 + a2, a3) : drgb_pack7(a1, a0 + a3, a2);
 						const uint32_t pxb = LAYOUT == VP_LAYOUT_RGGB ? drgb_pack7(b0, b1 + b2, b3) : drgb_pack7(b1, b0 + b3, b2);
-						const __amdgpu_buffer_rsrc_t rs = flat_rs(pp);
-						__builtin_amdgcn_raw_buffer_store_b32(pxa, rs, voff_out, 0u, NTS ? 2 : 0);
-						__builtin_amdgcn_raw_buffer_store_b32(pxb, rs, voff_out, fb_flat, NTS ? 2 : 0);
+						__builtin_amdgcn_raw_buffer_store_b32(pxa, wrs_flat, voff_out, (uint32_t)(2 * pp) * fb_flat, NTS ? 2 : 0);
+						__builtin_amdgcn_raw_buffer_store_b32(pxb, wrs_flat, voff_out, (uint32_t)(2 * pp + 1) * fb_flat, NTS ? 2 : 0);
 						if(agg) {
 							park_row(2 * pp, pxa);
 							park_row(2 * pp + 1, pxb);
@@ -837,7 +848,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					run_from(run_from, std::integral_constant<int, 0>());
 					if(fr_wg % FPS) { // a last incomplete sub-group
 						request(nsub_full, pre_a, fr_wg % FPS);
-						subgroup(std::false_type(), nsub_full, pre_a, fr_wg % FPS, false);
+						subgroup(nsub_full, pre_a, fr_wg % FPS);
 					}
 				} else {
 					for(int gi = 0; gi < nsub; gi++) {
@@ -845,7 +856,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 						if(g0 >= batch) break;
 						const int nfg = min(batch - g0, FPS);
 						request(gi, pre_a, nfg); // (what is left of the previous sub-group's stores is drained by the first wait: once per sub-group)
-						subgroup(std::false_type(), gi, pre_a, nfg, gi == 0);
+						subgroup(gi, pre_a, nfg);
 					}
 				}
 			};
