@@ -292,3 +292,42 @@ def test_resampling_groups_per_workgroup_on_the_unstaged_path(env, port):
                 assert np.array_equal(got[k], s["flat"]), (gpw, k)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fh", [3072, 4160], ids=["span_3_2_gb_one_descriptor", "span_4_4_gb_loop_form"])
+def test_resampling_workgroup_whose_frames_span_gigabytes_of_flat(env, port, fh):
+    """The written-out frame-pair stream addresses a workgroup's 64 frames through ONE buffer descriptor and scalar frame offsets, which must stay inside 32
+    bits.  Flat frames of 50 MB (4096 x 3072, configs[4]'s size): 64 of them span 3.2 GB -- a descriptor whose size has bit 31 set and offsets past 2 GiB.
+    Flat frames of 68 MB (4096 x 4160): 4.36 GB, so the kernel has to take its loop form (a descriptor per sub-group) instead -- silently, with the same
+    result.  66 frames (a workgroup's full 64 + 2): every frame against the byte-staged body of the same launch geometry (other descriptors, another
+    arithmetic path to the same integers), frames on both sides of the 64-frame boundary against the oracle's raw2quad + resampling."""
+    capi, torch = env
+    base = cfgs.T_MID
+    fw = 4096
+    fs = base.field_scale * base.fw / fw
+    cfg = base.with_(name=base.name + "_huge_flat", fw=fw, fh=fh, field_scale=fs)
+    assert (64 * fw * fh * 4 > 0xffffffff) == (fh == 4160) and 64 * fw * fh * 4 > 0x7fffffff and 16 * fw * fh * 4 < 0x7fffffff
+    B = 66
+    raws = np.stack([cfg.synth(6600 + i) for i in range(B)])
+    d_raw = torch.from_numpy(raws).cuda()
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        m = torch.zeros((fh, fw, 2), dtype=torch.float32, device="cuda")
+        ctx.resample_map(cfg.model(), cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, fw, fh, m)
+        flat = torch.zeros((B, fh, fw, 4), dtype=torch.uint8, device="cuda")
+        ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, m, cfg.sampler_mode, fw, fh, B, flat)
+        ctx.sync()
+        for k in (0, 63, 64, 65):
+            planes = port.raw2quad(raws[k], cfg.layout, cfg.qw, cfg.qh)
+            want = port.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode, fw, fh)
+            assert torch.equal(flat[k].cpu(), torch.from_numpy(want)), k
+        other = torch.zeros_like(flat)
+        ctx.tune("resample_float_stage", 0)
+        ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, m, cfg.sampler_mode, fw, fh, B, other)
+        ctx.sync()
+        for k in range(B):  # (frame by frame: torch.equal on 4.5 GB would make a 4.5 GB temporary)
+            assert torch.equal(flat[k], other[k]), k
+    finally:
+        ctx.close()
