@@ -331,3 +331,33 @@ def test_resampling_workgroup_whose_frames_span_gigabytes_of_flat(env, port, fh)
             assert torch.equal(flat[k], other[k]), k
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_resampling_full_stream_on_the_other_bayer_layout(env, port):
+    """The written-out 32-pair stream is a separate instantiation per Bayer layout (which sum is red, which two are the halved greens): GRBG with a
+    workgroup's full 64 frames + 6, frames on both sides of the boundary against the oracle, every frame against the byte-staged body."""
+    capi, torch = env
+    cfg = cfgs.T_MID.with_(name=cfgs.T_MID.name + "_grbg", layout=cfgs.GRBG)
+    B = 70
+    raws = np.stack([cfg.synth(6700 + i) for i in range(B)])
+    d_raw = torch.from_numpy(raws).cuda()
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        m = torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda")
+        ctx.resample_map(cfg.model(), cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, m)
+        flat = torch.zeros((B, cfg.fh, cfg.fw, 4), dtype=torch.uint8, device="cuda")
+        ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, m, cfg.sampler_mode, cfg.fw, cfg.fh, B, flat)
+        ctx.sync()
+        for k in (0, 1, 31, 62, 63, 64, 69):
+            planes = port.raw2quad(raws[k], cfg.layout, cfg.qw, cfg.qh)
+            want = port.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode, cfg.fw, cfg.fh)
+            assert torch.equal(flat[k].cpu(), torch.from_numpy(want)), k
+        other = torch.zeros_like(flat)
+        ctx.tune("resample_float_stage", 0)
+        ctx.resample_raw_mapped(d_raw, cfg.layout, cfg.qw, cfg.qh, m, cfg.sampler_mode, cfg.fw, cfg.fh, B, other)
+        ctx.sync()
+        assert torch.equal(flat, other)
+    finally:
+        ctx.close()
