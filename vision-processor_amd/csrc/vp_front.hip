@@ -772,6 +772,10 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					// the next pair's texels (from whichever set holds them) and ends with the one barrier.  The stream is LEFT, never skipped over, at the first
 					// sub-group the workgroup does not have (a forward exit: no wait-count state is merged on the path that goes on); a last incomplete sub-group
 					// takes the loop body below.
+					// What the stream's time is made of (ablations, profiles/r05_resample_issue_stream.json): the flat stores alone run at the chip's write rate, the
+					// dword-per-lane loads alone are bound by the CU's address unit, and together they take the SUM of their times whatever the loads' lead -- one
+					// in-order memory queue per CU; the four sums cost 4 %, the barrier nothing.  Tried against that and removed: chunked loads by one wavefront in
+					// turn, a fifth loading wavefront, two frames per load (v_permlane32_swap), predicated / out-of-range lanes past the box, deeper prefetch.
 					constexpr int PPS = FPS / 2, NP = VP_RS_NSUB * PPS; // pairs per sub-group, pairs in all
 					static_assert(VP_RS_NSUB % 2 == 0 && NP <= 64, "sub-groups come in pairs");
 					constexpr int NSETS = VP_RS_NSETS; // register sets of FPS dwords: sub-group s lives in set s % NSETS and is requested NSETS - 1 sub-groups ahead
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 					auto dw = [&](int pp, int k) -> uint32_t { // dword k (0 / 1) of pair pp: sub-group pp / PPS, frame 2 (pp % PPS) + k of it
 						return pre[(pp / PPS) % NSETS][2 * (pp % PPS) + k];
 					};
-					// ONE descriptor per buffer for the workgroup's frames, a frame = a scalar offset (the host-side condition below keeps every offset inside 32 bits);
+					// ONE descriptor per buffer for the workgroup's frames, a frame = a scalar offset (the condition above keeps every offset inside 32 bits);
 					// a descriptor per pair cost a 64-bit multiply-add in SALU instructions per pair and buffer
 					const __amdgpu_buffer_rsrc_t wrs_flat = __builtin_amdgcn_make_buffer_rsrc(flat + (size_t)f0 * npx * 4, 0, (int)((uint32_t)fr_wg * fb_flat), 0x00020000);
 					const __amdgpu_buffer_rsrc_t wrs_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(raw) + (size_t)f0 * src_frame_bytes, 0, (int)((uint32_t)fr_wg * fb_raw), 0x00020000);
