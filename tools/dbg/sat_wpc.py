@@ -1,5 +1,7 @@
-"""Resident workgroups per CU of the single-pass SAT (vp_ctx_tune "sat_workgroups_per_cu") at the benchmark launch: interleaved timing of vp_frame with the
-knob at 0 (automatic) / 4 / 5 / 6 in one process on one set of buffers.  GPU; tools only.  usage: sat_wpc.py [frames=256]"""
+"""Context-to-context spread of vp_frame at the benchmark launch: ten contexts with identical settings (sat_workgroups_per_cu 5; the even ones with
+"placement_candidates" 0, which only matters to builds that place their workspaces) in one process on one set of torch buffers, interleaved.  What differs
+between them is where their internal workspaces landed (profiles/r05_workspace_block_class.txt).  Edit the tuple below to compare values of the knob
+instead.  GPU; tools only.  usage: sat_wpc.py [frames=256]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
