@@ -18,8 +18,6 @@ runs = []
 for wpc in (5, 5, 5, 5, 5, 5, 5, 5, 5, 5):
     ctx = capi.Context(0, stream_ptr=torch.cuda.current_stream().cuda_stream)
     ctx.tune("sat_workgroups_per_cu", wpc)
-    if len(runs) % 2 == 0: ctx.tune("placement_candidates", 0)  # even contexts: workspaces from plain hipMalloc
-    ctx.events_enable(True) if hasattr(ctx, "events_enable") else None
     p = capi.frame_params(cfg)
     ctx.frame(p, raw, B, **d); ctx.sync()
     runs.append((len(runs), ctx, p))
@@ -31,4 +29,15 @@ for rnd in range(8):
         for _ in range(10): ctx.frame(p, raw, B, **d)
         e1.record(); torch.cuda.synchronize()
         res[wpc].append(e0.elapsed_time(e1) * 100)
-for wpc in res: print(f"context {wpc} ({'plain' if wpc % 2 == 0 else 'placed'} workspaces): vp_frame median {np.median(res[wpc]):8.1f} us per {B} frames (min {min(res[wpc]):.1f})")
+# per-stage times of each context (the library's own stage events), after the interleaved whole-frame timing
+stage = {}
+for wpc, ctx, p in runs:
+    ctx.events_enable(True); ctx.events_clear()
+    for _ in range(6): ctx.frame(p, raw, B, **d)
+    ctx.sync()
+    acc = {}
+    for name, ms in ctx.event_times(): acc.setdefault(name, []).append(ms)
+    stage[wpc] = {k: round(float(np.median(v)) * 1000, 1) for k, v in acc.items()}
+    ctx.events_enable(False)
+for wpc in res: print(f"   stages of context {wpc}: {stage[wpc]}")
+for wpc in res: print(f"context {wpc}: vp_frame median {np.median(res[wpc]):8.1f} us per {B} frames (min {min(res[wpc]):.1f})")
