@@ -148,6 +148,13 @@ int vph_detect_batch(VphDetector* const* ds, int n, const VpMatch* cl_matches, c
 int vph_detect_batch_slots(VphDetector* const* ds, int n, const uint8_t* slots, size_t slot_bytes, int max_matches, uint32_t frame_id, double start_time, double img_timestamp,
 		double t_sent, int threads, uint8_t* packet_block, int packet_slot_bytes);
 
+/* CLImage::save (opencl.h:204, opencl.cpp:161-179: cv::imwrite of a debug image as PNG): 8-bit greyscale (channels 1), RGB (3) or RGBA (4) pixels,
+ * tightly packed rows, as a PNG whose image data are stored (uncompressed) deflate blocks -- every decoder reads it, no zlib / OpenCV needed.
+ * VP_ERR_INVALID: bad arguments or the path cannot be opened. */
+int vph_write_png(const char* path, int w, int h, int channels, const uint8_t* pixels);
+/* the F32 branch of CLImage::save: out[i] = cv::saturate_cast<uint8_t>(factor * in[i] + offset) -- round to nearest even, saturate, NaN -> 0 */
+void vph_f32_to_grey(const float* in, size_t n, float factor, float offset, uint8_t* out);
+
 /* building blocks, exported for the unit tests */
 float vph_atan2_fast(float y, float x);                                                              /* hypothesis.cpp:35-58 */
 int vph_kmeans(const int32_t contrast[3], const int32_t* values, int n, int32_t c1[3], int32_t c2[3]); /* kmeans.cpp:19-90 */

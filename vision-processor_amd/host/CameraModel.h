@@ -17,7 +17,7 @@
 namespace vp {
 
 struct Vec2f { float x = 0.f, y = 0.f; };
-struct Vec2i { int x = 0, y = 0; bool operator==(const Vec2i& o) const { return x == o.x && y == o.y; } };
+struct Vec2i { int x = 0, y = 0; bool operator==(const Vec2i& o) const { return x == o.x && y == o.y; } int& operator[](int i) { return i ? y : x; } int operator[](int i) const { return i ? y : x; } }; // [] as Eigen::Vector2i (Resources.cpp:152: reprojectedFieldSize[0])
 struct Vec3f { float x = 0.f, y = 0.f, z = 0.f; };
 struct Vec4f { float v[4] = {0, 0, 0, 0}; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
 struct Quatf { float w = 0.f, x = -1.f, y = 0.f, z = 0.f; };

@@ -1,7 +1,8 @@
 // CALLER SIDE of the drop-in, not product logic.  raw2quad(), quad2rgba(), rgba2blobCenter(), streamQuad() and streamImage() below are the
-// reference's own call sequences (src/Resources.cpp:138-186) written down again, statement for statement, against the facade of host/opencl.h:
-// their point is to show -- and, through tests/test_gpu_facade.py, to check on the GPU -- that the reference's call sites compile and run
-// unchanged on the new runtime.  Nothing here computes anything; the work happens behind OpenCL::run / await in libvp_hip.so.
+// reference's call sequences (src/Resources.cpp:138-186) PARAPHRASED against the facade of host/opencl.h (the repeated expressions get names), so that
+// the facade demo builds and runs on a box without the reference tree (tests/test_gpu_facade.py).  That the reference's REAL text of those functions
+// compiles against this facade is checked where the reference exists: tests/test_reference_callsites.py.  Nothing here computes anything; the work
+// happens behind OpenCL::run / await in libvp_hip.so.
 #include "Resources.h"
 
 #include <vector>
@@ -52,7 +53,7 @@ void Resources::rgba2blobCenter(const std::shared_ptr<CLImage>* channels, std::s
 	blobCenter = openCl->acquire(&PixelFormat::F32, fw, fh, name);
 
 	cl::Event e1 = openCl->run(resampling, cl::EnqueueArgs(field), channels[0]->image, channels[1]->image, channels[2]->image, channels[3]->image, flat->image, p.getCLCameraModel(),
-			(float)maxBotHeight, p.fieldScale, p.visibleFieldExtent[0], p.visibleFieldExtent[2]);
+			(float)gcSocket->maxBotHeight, p.fieldScale, p.visibleFieldExtent[0], p.visibleFieldExtent[2]);
 	cl::Event e2 = openCl->run(gradientDot, cl::EnqueueArgs(e1, field), flat->image, gradDot->image, p.gradOffset());
 	cl::Event e3 = openCl->run(satHorizontal, cl::EnqueueArgs(e2, cl::NDRange(fh)), gradDot->image, gradDotHor->image);
 	cl::Event e4 = openCl->run(satVertical, cl::EnqueueArgs(e3, cl::NDRange(fw)), gradDotHor->image, gradDotSat->image);

@@ -88,10 +88,10 @@ void vph_config_defaults(VphConfig* cfg) {
 	cfg->history_force = d.historyForce;
 	const vp::Vec3i refs[6] = {d.orangeReference, d.fieldReference, d.yellowReference, d.blueReference, d.greenReference, d.pinkReference};
 	for(int i = 0; i < 6; i++) put3(cfg->reference_colors[i], refs[i]);
-	cfg->max_bot_height = d.maxBotHeight;
-	cfg->default_bot_height = d.defaultBotHeight;
-	cfg->yellow_bot_height = d.yellowBotHeight;
-	cfg->blue_bot_height = d.blueBotHeight;
+	cfg->max_bot_height = d.gcSocket->maxBotHeight;
+	cfg->default_bot_height = d.gcSocket->defaultBotHeight;
+	cfg->yellow_bot_height = d.gcSocket->yellowBotHeight;
+	cfg->blue_bot_height = d.gcSocket->blueBotHeight;
 }
 
 VphDetector* vph_detector_create(const VphConfig* cfg) {
@@ -115,10 +115,10 @@ VphDetector* vph_detector_create(const VphConfig* cfg) {
 	r.green = r.greenReference = v3(cfg->reference_colors[4]);
 	r.pink = r.pinkReference = v3(cfg->reference_colors[5]);
 	r.fieldLineColor = r.fieldReference;
-	r.maxBotHeight = cfg->max_bot_height;
-	r.defaultBotHeight = cfg->default_bot_height;
-	r.yellowBotHeight = cfg->yellow_bot_height;
-	r.blueBotHeight = cfg->blue_bot_height;
+	r.gcSocket->maxBotHeight = cfg->max_bot_height;
+	r.gcSocket->defaultBotHeight = cfg->default_bot_height;
+	r.gcSocket->yellowBotHeight = cfg->yellow_bot_height;
+	r.gcSocket->blueBotHeight = cfg->blue_bot_height;
 	r.perspective = std::make_shared<vp::Perspective>(r.camId, r.geometryTolerance);
 	return d;
 }
@@ -131,7 +131,7 @@ int vph_detector_set_geometry(VphDetector* d, const float calib[11], int calib_w
 	const vp::FieldSize f = fieldFrom(field, ball_radius, max_robot_radius, lines, n_lines, arcs, n_arcs);
 	const vp::CameraCalibration c = calibFrom(calib, d->r.camId, calib_w, calib_h);
 	d->r.perspective->setGeometry(f, &c, 1);
-	d->r.perspective->geometryCheck(img_w, img_h, d->r.maxBotHeight, resampling_factor);
+	d->r.perspective->geometryCheck(img_w, img_h, d->r.gcSocket->maxBotHeight, resampling_factor);
 	d->r.ballRadius = ball_radius; // udpsocket.cpp:123-124
 	return d->r.perspective->geometryVersion ? VP_OK : VP_ERR_INVALID;
 }
@@ -383,7 +383,7 @@ static int applyGeometry(VphDetector* d, const vp::FieldSize& field, const std::
 	vp::Perspective& p = *d->r.perspective;
 	const int before = p.geometryVersion;
 	p.setGeometry(field, calibs.data(), (int)calibs.size());
-	p.geometryCheck(img_w, img_h, d->r.maxBotHeight, resampling_factor);
+	p.geometryCheck(img_w, img_h, d->r.gcSocket->maxBotHeight, resampling_factor);
 	bool mine = false;
 	for(const vp::CameraCalibration& c : calibs) mine |= c.camera_id == (uint32_t)d->r.camId;
 	if(!mine || !p.geometryVersion || p.geometryVersion == before) return 0;
@@ -408,7 +408,7 @@ static int applyGeometry(VphDetector* d, const vp::FieldSize& field, const std::
 
 int vph_udp_open(VphDetector* d, const char* ip, int port) {
 	if(!d || !ip || port <= 0 || port > 65535) return VP_ERR_INVALID;
-	d->socket = std::make_unique<vp::VisionSocket>(ip, (uint16_t)port, d->r.camId, (float)d->r.defaultBotHeight);
+	d->socket = std::make_unique<vp::VisionSocket>(ip, (uint16_t)port, d->r.camId, (float)d->r.gcSocket->defaultBotHeight);
 	if(!d->socket->ok()) {
 		d->socket.reset();
 		return VP_ERR_INVALID;
@@ -449,19 +449,19 @@ int vph_gc_open(VphDetector* d, const char* ip, int port, const char* const* nam
 		d->gcSocket.reset();
 		return VP_ERR_INVALID;
 	}
-	d->gcSocket->heights(d->r.maxBotHeight, d->r.defaultBotHeight, d->r.yellowBotHeight, d->r.blueBotHeight);
+	d->gcSocket->heights(d->r.gcSocket->maxBotHeight, d->r.gcSocket->defaultBotHeight, d->r.gcSocket->yellowBotHeight, d->r.gcSocket->blueBotHeight);
 	return VP_OK;
 }
 
 int vph_gc_sync(VphDetector* d, int at_least, int timeout_ms, double heights_out[4]) {
 	if(!d || !d->gcSocket) return VP_ERR_INVALID;
 	const bool ok = d->gcSocket->waitForPackets(at_least, timeout_ms);
-	d->gcSocket->heights(d->r.maxBotHeight, d->r.defaultBotHeight, d->r.yellowBotHeight, d->r.blueBotHeight);
+	d->gcSocket->heights(d->r.gcSocket->maxBotHeight, d->r.gcSocket->defaultBotHeight, d->r.gcSocket->yellowBotHeight, d->r.gcSocket->blueBotHeight);
 	if(heights_out) {
-		heights_out[0] = d->r.maxBotHeight;
-		heights_out[1] = d->r.defaultBotHeight;
-		heights_out[2] = d->r.yellowBotHeight;
-		heights_out[3] = d->r.blueBotHeight;
+		heights_out[0] = d->r.gcSocket->maxBotHeight;
+		heights_out[1] = d->r.gcSocket->defaultBotHeight;
+		heights_out[2] = d->r.gcSocket->yellowBotHeight;
+		heights_out[3] = d->r.gcSocket->blueBotHeight;
 	}
 	return ok ? d->gcSocket->receivedPackets() : -1;
 }

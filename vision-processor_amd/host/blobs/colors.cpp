@@ -45,7 +45,7 @@ float segmentDistanceSq(const FieldLine& segment, const Vec2f& q) {
 // tolerance)?  colorupdate.cpp:32-55
 bool onFieldMarking(const BlobResources& r, const BallHypothesis& candidate) {
 	const Perspective& view = *r.perspective;
-	const Vec2f pixel = view.model.field2image({candidate.pos.x, candidate.pos.y, (float)r.maxBotHeight});
+	const Vec2f pixel = view.model.field2image({candidate.pos.x, candidate.pos.y, (float)r.gcSocket->maxBotHeight});
 	const Vec3f onGround = view.model.image2field(pixel, view.field.ball_radius);
 	const Vec2f q{onGround.x, onGround.y};
 	const float reach = (float)view.field.line_thickness / 2 + r.geometryTolerance;

@@ -103,6 +103,13 @@ struct DetectionFrame {
 	std::vector<DetectionRobot> robots_yellow, robots_blue;
 };
 
+struct BotHeights { // udpsocket.h:121-128, defaults of the shipped robot-heights.yml
+	double maxBotHeight = 180.0;
+	double defaultBotHeight = 143.0;
+	double yellowBotHeight = 143.0;
+	double blueBotHeight = 143.0;
+};
+
 // The members of the reference's Resources / GCSocket / VisionSocket that this stage reads and writes (Resources.h:43-73,
 // udpsocket.h:106,122-128), defaults as in Resources.cpp:84-85,189-209 and the shipped robot-heights.yml.
 struct BlobResources {
@@ -121,11 +128,10 @@ struct BlobResources {
 	Vec3i orange = orangeReference, field = fieldReference, yellow = yellowReference, blue = blueReference, green = greenReference, pink = pinkReference;
 	Vec3i fieldLineColor = fieldReference;
 
-	// gcSocket
-	double maxBotHeight = 180.0;
-	double defaultBotHeight = 143.0;
-	double yellowBotHeight = 143.0;
-	double blueBotHeight = 143.0;
+	// The reference reaches the four robot heights through its game-controller socket (Resources.h:91 `gcSocket`, udpsocket.h:121-128: public doubles):
+	// `r.gcSocket->maxBotHeight` at Resources.cpp:159, main.cpp:273, hypothesis.cpp:71,143-144.  Same spelling here, so those statements compile unchanged
+	// (tests/test_reference_callsites.py); vp::GCSocket, the UDP receiver, refreshes them through heights().
+	std::shared_ptr<BotHeights> gcSocket = std::make_shared<BotHeights>();
 
 	// socket: what VisionSocket::getTrackedObjects / getReceivedOffsets hand out
 	std::map<unsigned int, std::vector<TrackingState>> trackedObjects;

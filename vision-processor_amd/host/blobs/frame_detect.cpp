@@ -22,7 +22,7 @@ bool closerThanCamEdgeDistance(const BlobResources& r, const Vec2f& pos, const V
 	const FieldSize& field = r.perspective->field;
 	const float halfFieldLength = field.field_length / 2 + goalBoundaryWidth(field);
 	const float halfFieldWidth = (float)(field.field_width / 2 + field.boundary_width);
-	const Vec3f b3 = r.perspective->model.image2field(border, (float)r.maxBotHeight);
+	const Vec3f b3 = r.perspective->model.image2field(border, (float)r.gcSocket->maxBotHeight);
 	const Vec2f borderPos{b3.x, b3.y};
 	// a border point outside the field cannot cut a robot or ball in half
 	const bool borderInsideField = borderPos.x >= -halfFieldLength && borderPos.x <= halfFieldLength && borderPos.y >= -halfFieldWidth && borderPos.y <= halfFieldWidth;
@@ -78,7 +78,7 @@ void generateRadiusSearchTrackedBotHypotheses(const BlobResources& r, std::vecto
 			if(tracked.id == -1) continue;
 
 			float timeDelta = (float)(currentTimestamp - tracked.timestamp);
-			const Vec3f reprojected = model.image2field(model.field2image({tracked.x, tracked.y, tracked.z}), (float)r.maxBotHeight);
+			const Vec3f reprojected = model.image2field(model.field2image({tracked.x, tracked.y, tracked.z}), (float)r.gcSocket->maxBotHeight);
 			const Vec3f trackedPosition{reprojected.x + tracked.vx * timeDelta, reprojected.y + tracked.vy * timeDelta, tracked.w + tracked.vw * timeDelta};
 			const Rot2 rotation(trackedPosition.z);
 
@@ -136,7 +136,7 @@ void filterStddevScore(std::vector<BallHypothesis>& balls, float threshold) { //
 void filterBallsAtCamEdge(const BlobResources& r, std::vector<BallHypothesis>& balls) { // :170-187
 	const CameraModel& model = r.perspective->model;
 	eraseIf(balls, [&](const BallHypothesis& ball) {
-		const Vec2f imgPos = model.field2image({ball.pos.x, ball.pos.y, (float)r.maxBotHeight});
+		const Vec2f imgPos = model.field2image({ball.pos.x, ball.pos.y, (float)r.gcSocket->maxBotHeight});
 		return closerThanCamEdgeDistance(r, ball.pos, {0.0f, imgPos.y}) || closerThanCamEdgeDistance(r, ball.pos, {(float)(model.size.x - 1), imgPos.y}) ||
 				closerThanCamEdgeDistance(r, ball.pos, {imgPos.x, 0.0f}) || closerThanCamEdgeDistance(r, ball.pos, {imgPos.x, (float)(model.size.y - 1)});
 	});

@@ -223,7 +223,7 @@ bool isClipping(const BlobResources& r, const BotHypothesis& self, const BallHyp
 
 void addToDetectionFrame(const BlobResources& r, const BallHypothesis& ball, DetectionFrame& detection) {
 	const CameraModel& model = r.perspective->model;
-	const Vec2f imgPos = model.field2image({ball.pos.x, ball.pos.y, (float)r.maxBotHeight});
+	const Vec2f imgPos = model.field2image({ball.pos.x, ball.pos.y, (float)r.gcSocket->maxBotHeight});
 	const Vec3f ballPos = model.image2field(imgPos, r.perspective->field.ball_radius);
 	detection.balls.push_back({ball.score, ballPos.x, ballPos.y, imgPos.x, imgPos.y});
 }
@@ -231,8 +231,8 @@ void addToDetectionFrame(const BlobResources& r, const BallHypothesis& ball, Det
 void addToDetectionFrame(const BlobResources& r, const BotHypothesis& bot, DetectionFrame& detection) {
 	const CameraModel& model = r.perspective->model;
 	const bool yellow = bot.botId < 16;
-	const Vec2f imgPos = model.field2image({bot.pos.x, bot.pos.y, (float)r.maxBotHeight});
-	const Vec3f botPos = model.image2field(imgPos, (float)(yellow ? r.yellowBotHeight : r.blueBotHeight));
+	const Vec2f imgPos = model.field2image({bot.pos.x, bot.pos.y, (float)r.gcSocket->maxBotHeight});
+	const Vec3f botPos = model.image2field(imgPos, (float)(yellow ? r.gcSocket->yellowBotHeight : r.gcSocket->blueBotHeight));
 	// botId % 16 is assigned to a uint32 field; a tracked id is never negative here (id -1 entries are skipped, main.cpp:87-88)
 	(yellow ? detection.robots_yellow : detection.robots_blue).push_back({bot.score, (uint32_t)(bot.botId % 16), botPos.x, botPos.y, bot.orientation, imgPos.x, imgPos.y, botPos.z});
 }

@@ -191,7 +191,7 @@ struct VisionSocket::State {
 };
 
 VisionSocket::VisionSocket(const std::string& ip, uint16_t port, int camId, float defaultBotHeight): UDPSocket(ip, port), state(new State()), camId(camId) {
-	state->tracker.defaultBotHeight = defaultBotHeight;
+	state->tracker.gcSocket->defaultBotHeight = defaultBotHeight;
 	start();
 }
 

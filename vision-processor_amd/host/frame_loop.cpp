@@ -77,7 +77,7 @@ int main(int argc, char* argv[]) {
 		std::shared_ptr<RawImage> img = r.camera->readImage();
 		if(img == nullptr) break;
 		const double startTime = r.camera->getTime(); // main.cpp:270
-		if(mode != "direct") p.geometryCheck(img->width, img->height, r.maxBotHeight, r.resamplingFactor);
+		if(mode != "direct") p.geometryCheck(img->width, img->height, r.gcSocket->maxBotHeight, r.resamplingFactor);
 		std::shared_ptr<CLImage> channels[4];
 		r.raw2quad(*img, channels);
 		if(!p.geometryVersion) continue; // main.cpp:277

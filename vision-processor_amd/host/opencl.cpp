@@ -1,5 +1,6 @@
 // See opencl.h.  Implements the facade over the C ABI of libvp_hip.so (include/vp_hip.h).
 #include "opencl.h"
+#include "vp_host.h"
 
 const PixelFormat PixelFormat::RGBA8(4, 1, true, -1, "");
 const PixelFormat PixelFormat::U8(1, 1, false, -1, "");
@@ -161,6 +162,30 @@ static std::shared_ptr<VpBuffer> bufferCreate(size_t bytes, const void* init) {
 CLArray::CLArray(int size): buffer{nullptr}, size(size), object(bufferCreate((size_t)size, nullptr)) { const_cast<cl::Buffer&>(buffer).dptr = vp_buffer_device(object.get()); }
 CLArray::CLArray(void* data, int size): buffer{nullptr}, size(size), object(bufferCreate((size_t)size, data)) { // CL_MEM_COPY_HOST_PTR (opencl.cpp:147)
 	const_cast<cl::Buffer&>(buffer).dptr = vp_buffer_device(object.get());
+}
+
+// opencl.cpp:161-179.  RGBA8 -> the three colour channels (the reference converts RGBA to BGR for cv::imwrite, which stores RGB); F32 -> grey through
+// factor / offset; anything else (U8 planes) -> grey as it is.
+void CLImage::save(const std::string& suffix, float factor, float offset) const {
+	const std::string path = "img/" + name + suffix;
+	const size_t n = (size_t)width * height;
+	std::vector<uint8_t> px;
+	int channels = 1;
+	if(format == &PixelFormat::F32) {
+		CLImageMap<float> map = read<float>();
+		px.resize(n);
+		vph_f32_to_grey(*map, n, factor, offset, px.data());
+	} else if(format == &PixelFormat::RGBA8) {
+		CLImageMap<uint8_t> map = read<uint8_t>();
+		channels = 3;
+		px.resize(3 * n);
+		for(size_t i = 0; i < n; i++)
+			for(int c = 0; c < 3; c++) px[3 * i + c] = map[4 * i + c];
+	} else {
+		CLImageMap<uint8_t> map = read<uint8_t>();
+		px.assign(*map, *map + n); // U8 planes (the only other image format the pool hands out)
+	}
+	if(vph_write_png(path.c_str(), width, height, channels, px.data()) != VP_OK) WARN("could not write " << path);
 }
 
 CLImage::CLImage(const PixelFormat* format): format(format), width(0), height(0) {}

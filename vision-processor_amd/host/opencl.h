@@ -4,7 +4,9 @@
 // the C ABI (include/vp_hip.h), `OpenCL::run` forwards the argument pack to it, images and buffers are plain HIP memory.
 //
 // Differences a maintainer will notice (all deliberate):
-//   * CLImageMap has no `cv::Mat cv` member (OpenCV is not a dependency of the hot path); rowPitch == width.
+//   * CLImageMap has no `cv::Mat cv` member (OpenCV is not a dependency of the hot path); rowPitch == width.  It is the ONE member of the
+//     reference's opencl.h this header lacks: tests/test_reference_callsites.py compiles the reference's own text of Resources.cpp:138-164 and
+//     the GPU statements of main.cpp:253-317 against this header.
 //   * map()/unmap() are a device<->pinned-host copy on the context stream (the reference's blocking clEnqueueMapBuffer).
 //   * the intermediate SAT is an int32 table owned by Resources::rgba2blobCenter, never exposed (the reference keeps its
 //     two F32 SAT images private to that function as well, Resources.cpp:155-156).
@@ -148,6 +150,8 @@ public:
 	T*& operator*() { return map; }
 	T* operator->() { return map; }
 	T& operator[](int i) { return map[i]; }
+	const T* const& operator*() const { return reinterpret_cast<const T* const&>(map); } // opencl.h:139-141 (`const T*` and `T*` are similar types: the same object, no temporary)
+	const T* operator->() const { return map; }
 	const T& operator[](int i) const { return map[i]; }
 
 private:
@@ -175,7 +179,9 @@ private:
 
 class RawImage: public CLArray { // opencl.h:168-188 -- for Bayer formats width/height count 2x2 cells
 public:
+	RawImage(const RawImage& other) = default; // opencl.h:170: shares the device buffer (here: the shared VpBuffer), as copying a cl::Buffer handle does
 	RawImage(const PixelFormat* format, int width, int height): CLArray(width * height * format->pixelSize()), format(format), width(width), height(height), name() {}
+	RawImage(CLArray array, const PixelFormat* format, int width, int height, std::string name): CLArray(std::move(array)), format(format), width(width), height(height), name(std::move(name)) {} // opencl.h:172
 	RawImage(const PixelFormat* format, int width, int height, std::string name): CLArray(width * height * format->pixelSize()), format(format), width(width), height(height), name(std::move(name)) {}
 	RawImage(const PixelFormat* format, int width, int height, double timestamp): CLArray(width * height * format->pixelSize()), format(format), width(width), height(height), timestamp(timestamp), name() {}
 	RawImage(const PixelFormat* format, int width, int height, unsigned char* data): CLArray(data, width * height * format->pixelSize()), format(format), width(width), height(height) {}
@@ -199,6 +205,10 @@ public:
 	template<typename T> CLImageMap<T> read() const { return CLImageMap<T>(*this, true, false); }
 	template<typename T> CLImageMap<T> write() { return CLImageMap<T>(*this, false, true); }
 	template<typename T> CLImageMap<T> readWrite() { return CLImageMap<T>(*this, true, true); }
+
+	// opencl.h:204, opencl.cpp:161-179: "img/" + name + suffix as an 8-bit PNG -- F32: saturate(round(factor * v + offset)) grey, RGBA8: RGB, else grey.
+	// Written by vph_write_png (include/vp_host.h), no OpenCV; a path that cannot be opened is a WARN (cv::imwrite returns false there).
+	void save(const std::string& suffix, float factor = 1.0f, float offset = 0.0f) const;
 
 	cl::Image2D image;
 	const PixelFormat* format;
@@ -234,6 +244,8 @@ public:
 	T& operator[](int i) { return map[i]; }
 	T& operator()(int x, int y) { return map[x + y * rowPitch]; }
 	const T& operator()(int x, int y) const { return map[x + y * rowPitch]; }
+	const T* const& operator*() const { return reinterpret_cast<const T* const&>(map); } // opencl.h:247-249
+	const T* operator->() const { return map; }
 	const T& operator[](int i) const { return map[i]; }
 
 	size_t bytePitch;
