@@ -110,7 +110,11 @@ const char* vp_device_name(VpContext* ctx);
  *   buffers) call into a hipGraph when the call follows itself on the stream and replays the graph from then on; a stream whose state belongs to another
  *   tuple -- another launch shape, another geometry -- takes the ordinary path, which repairs it; calls with stage events enabled or debug views always
  *   do.  2 = the same without the pre-flight check: every repeated tuple attempts a capture, and a capture that meets a repair is refused and undone --
- *   slower, for tests of that path).  Applies to calls issued after it. */
+ *   slower, for tests of that path), "sat_spin_limit" n (0 = 2^22: polls a look-back wait of the single-pass SAT may take before the launch gives up --
+ *   vp_sync then returns VP_ERR_TIMEOUT and the stream's next SAT launch resets the carry state; seconds by default, never reached in a healthy run).
+ *   Applies to calls issued after it.
+ * NOT result-neutral, for tests of the recovery path only: "sat_debug_drop_tile" t (-1 = off): the single-pass SAT withholds the column carry of tile t
+ *   (frame * tiles per frame + row * tiles per row + column) of its launches, so that the tile below waits for the limit above and the launch times out. */
 int vp_ctx_tune(VpContext* ctx, const char* key, int value);
 /* "frame_graph" bookkeeping since the context was created: out = {captures made, replays launched, captures refused and undone, graphs dropped because the
  * stream's state had moved}. */

@@ -1,0 +1,103 @@
+"""GPU tests added in round 6, all through the C ABI.
+
+  * the library's one recovery path, executed: a look-back wait of the single-pass SAT that never ends -> bounded launch -> VP_ERR_TIMEOUT from vp_sync
+    -> the stream's next launch resets the carry state and is correct again; other streams of the context never notice.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import cases
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+cfgs = cases.cfgs
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return cases.vp.load_capi(), torch
+
+
+def oracle_frame(port, cfg, raw, mm):
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    return port.frame(raw, cfg.layout, cfg.qw, cfg.qh, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.sampler_mode,
+                      cfg.fw, cfg.fh, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, mm)
+
+
+class Buffers:
+    def __init__(self, torch, cfg, batch, mm):
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+        self.flat, self.sat = z((batch, cfg.fh, cfg.fw, 4), torch.uint8), z((batch, cfg.fh, cfg.fw), torch.int32)
+        self.m, self.idx, self.cnt = z((batch, mm * 22), torch.uint8), z((batch, mm), torch.int32), z((batch, 3), torch.int32)
+
+    def kw(self):
+        return dict(flat=self.flat, sat=self.sat, matches=self.m, counter=self.cnt, idx=self.idx)
+
+
+def check(capi, b, f, want, mm):
+    wm, widx, wcnt = want
+    cnt = b.cnt[f].cpu().numpy()
+    assert np.array_equal(cnt, wcnt), (cnt, wcnt)
+    gm, gi = capi.sorted_blobs(b.m[f].cpu().numpy(), b.idx[f].cpu().numpy().view(np.uint32), cnt, mm)
+    assert np.array_equal(gi, widx) and gm.tobytes() == wm.tobytes()
+
+
+def test_a_lookback_wait_that_never_ends_is_bounded_reported_and_recovered_from(env, port):
+    """The only way a carry hand-off bug of the single-pass SAT (vp_sat_tiled.hip) would ever reach a caller, run once on purpose.
+
+    vp_ctx_tune("sat_debug_drop_tile", t) makes the launch withhold the column carry of tile t -- neither the aggregate nor the inclusive granule is
+    published -- so the tile below it polls until "sat_spin_limit" runs out (set small here; seconds by default), raises the device abort word and the
+    pinned host flag, every other waiting wavefront sees the abort and leaves, and the launch DRAINS (a kernel that spun for ever would take the GPU
+    with it).  Then, as opencl.cpp:87-92 turns a failed wait into FATAL: vp_sync returns VP_ERR_TIMEOUT with a message (the facade's VP_OR_FATAL exits
+    on it); the table of that launch is wrong, as documented.  The caller's NEXT vp_frame on the stream finds the flag, resets the carry state
+    (tickets, epochs, granules: vp_sat_tiled.hip `reset`) and returns the oracle's frame; a launch on another stream of the same context, issued
+    between the two, never notices.  Three frames per launch so that frames beside the poisoned one are seen to be caught by the abort, too."""
+    capi, torch = env
+    cfg, mm, B = cfgs.T_MID, cfgs.T_MID.max_matches, 3
+    raws = [cfg.synth(9100 + i) for i in range(B)]
+    want = [oracle_frame(port, cfg, r, mm) for r in raws]
+    assert min(int(w[2][0]) for w in want) >= 20
+    d_raw = torch.from_numpy(np.stack(raws)).cuda()
+    ctx = capi.Context(0, n_streams=2)
+    try:
+        ctx.tune("sat_spin_limit", 4000)
+        p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+        b0, b1 = Buffers(torch, cfg, B, mm), Buffers(torch, cfg, B, mm)
+        # a healthy launch first: the stream has live carry state (epoch 1) when the fault comes
+        ctx.frame(p, d_raw, B, stream=0, **b0.kw())
+        ctx.sync(0)
+        for f in range(B): check(capi, b0, f, want[f], mm)
+        good_sat = b0.sat.clone()
+
+        tiles_x = (cfg.fw + 63) // 64
+        ctx.tune("sat_debug_drop_tile", 1 * tiles_x * ((cfg.fh + 63) // 64) + 3)   # frame 1, tile row 0, tile column 3: the tiles below it starve
+        ctx.frame(p, d_raw, B, stream=0, **b0.kw())
+        ctx.tune("sat_debug_drop_tile", -1)
+        ctx.frame(p, d_raw, B, stream=1, **b1.kw())                                    # another stream of the same context, same time
+        t0 = time.perf_counter()
+        ctx.sync(1)                                                                    # healthy: no error, the oracle's frames
+        for f in range(B): check(capi, b1, f, want[f], mm)
+        with pytest.raises(capi.VpError) as e:
+            ctx.sync(0)
+        waited = time.perf_counter() - t0
+        assert e.value.code == -4 and "look-back" in str(e.value), str(e.value)         # VP_ERR_TIMEOUT (include/vp_hip.h)
+        assert waited < 20.0, f"the poisoned launch took {waited:.1f} s to drain"
+        assert not torch.equal(b0.sat[1], good_sat[1]), "the fault was not injected: the table of the poisoned frame is right"
+        with pytest.raises(capi.VpError):                                               # the flag stays up until a launch has repaired the stream
+            ctx.sync(0)
+        ctx.sync(1)
+
+        # recovery: the next call on the poisoned stream resets and is right again -- twice, so that the state after the reset is seen to be live
+        for _ in range(2):
+            b0.sat.zero_(); b0.cnt.fill_(77)
+            ctx.frame(p, d_raw, B, stream=0, **b0.kw())
+            ctx.sync(0)
+            assert torch.equal(b0.sat, good_sat)
+            for f in range(B): check(capi, b0, f, want[f], mm)
+        ctx.sync()
+    finally:
+        ctx.close()

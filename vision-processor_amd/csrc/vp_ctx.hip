@@ -139,6 +139,12 @@ extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {
 	} else if(k == "tail_emit_kernel") {
 		VP_REQUIRE(value == 0 || value == 1, "vp_ctx_tune: tail_emit_kernel is 0 or 1");
 		ctx->tune.tail_emit_kernel = value;
+	} else if(k == "sat_spin_limit") {
+		VP_REQUIRE(value >= 0, "vp_ctx_tune: sat_spin_limit: polls per look-back wait, 0 = default (2^22)");
+		ctx->tune.sat_spin_limit = value;
+	} else if(k == "sat_debug_drop_tile") {
+		VP_REQUIRE(value >= -1, "vp_ctx_tune: sat_debug_drop_tile: a tile index of the launch, or -1 (off)");
+		ctx->tune.sat_debug_drop_tile = value;
 	} else if(k == "tail_segment_rows") {
 		VP_REQUIRE(value >= 0 && value <= 4096, "vp_ctx_tune: tail_segment_rows out of range [0,4096]");
 		ctx->tune.tail_segment_rows = value;

@@ -34,7 +34,7 @@ typedef __attribute__((address_space(1))) uint32_t gu32;
 namespace {
 
 constexpr int TW = 64, TH = 64, NWAVES = 4, SEG = TH / NWAVES;
-constexpr unsigned SPIN_LIMIT = 1u << 22; // polls (each with s_sleep): seconds, never reached in a healthy run
+constexpr unsigned SPIN_LIMIT = 1u << 22; // polls (each with s_sleep) a look-back wait may take by default: seconds, never reached in a healthy run (vp_ctx_tune "sat_spin_limit")
 constexpr uint32_t ST_AGG = 1, ST_INC = 2;
 
 struct TiledArgs {
@@ -50,6 +50,10 @@ struct TiledArgs {
 	VpStrips strips; // optional halo strips (base == nullptr: halo columns are read from flat)
 	int single;     // k_sat_fast2: as many workgroups as tiles per frame -- each takes ONE ticket and none in advance
 	int32_t* zero;  // optional: int[3 x batch] cleared by the first workgroup of each frame (the blob list's counters, main.cpp:283-288)
+	uint32_t spin_limit; // polls before a look-back wait gives up (raise_timeout)
+	int drop_tile;       // fault injection (vp_ctx_tune "sat_debug_drop_tile", tests only; -1 = none): the column chain of this tile (frame * tiles + ti * tilesX + tj) publishes NOTHING,
+	                     // so the tile below it waits until the limit, raises the timeout and the launch drains with a wrong table -- the library's one recovery path, exercised by
+	                     // tests/test_gpu_round6.py.  One scalar compare per tile.
 };
 
 __device__ __forceinline__ u64 ld_granule(const u64* p) {
@@ -96,7 +100,7 @@ __device__ __forceinline__ bool lookback(const u64* g, long stride, int npred, c
 			for(unsigned spins = 0;; spins++) {
 				const bool ready = done || ((tag >> 2) == a.epoch && (tag & 3u) != 0);
 				if(__all(ready)) break;
-				if(spins > SPIN_LIMIT || ((spins & 63u) == 63u && aborted(a))) {
+				if(spins > a.spin_limit || ((spins & 63u) == 63u && aborted(a))) {
 					if((threadIdx.x & 63) == 0) raise_timeout(a);
 					return false;
 				}
@@ -241,11 +245,12 @@ __global__ __launch_bounds__(256) void k_sat_tiled(const void* __restrict__ in, 
 			const int pc = T[lane] + T[TW + lane] + T[2 * TW + lane] + T[3 * TW + lane]; // bottom row of the local SAT
 			u64* g = a.V + tile * TW + lane;
 			int carry = 0;
+			const bool drop = (long)tile == (long)a.drop_tile; // fault injection, see TiledArgs
 			if(ti > 0) {
-				st_granule(g, a.epoch, ST_AGG, pc);
+				if(!drop) st_granule(g, a.epoch, ST_AGG, pc);
 				lookback(g, (long)a.tilesX * TW, ti, a, carry);
 			}
-			st_granule(g, a.epoch, ST_INC, carry + pc);
+			if(!drop) st_granule(g, a.epoch, ST_INC, carry + pc);
 			Av[lane] = carry;
 		} else if(wv == 1) { // row chain: B(y), then the corner chain's aggregate Q = B(TH-1)
 			const bool act = lane < TH;
@@ -578,11 +583,12 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 			asm volatile("" : "+v"(lanev));
 			u64* g = a.V + tile * TW + lanev;
 			int carry = 0;
+			const bool drop = (long)tile == (long)a.drop_tile; // fault injection, see TiledArgs (scalar: tile is workgroup-uniform)
 			if(ti > 0 && !early_resolve(pre0, pre1, ti, a, carry)) {
-				st_granule(g, a.epoch, ST_AGG, pc);
+				if(!drop) st_granule(g, a.epoch, ST_AGG, pc);
 				lookback(g, (long)a.tilesX * TW, ti, a, carry);
 			}
-			st_granule(g, a.epoch, ST_INC, carry + pc);
+			if(!drop) st_granule(g, a.epoch, ST_INC, carry + pc);
 			Av[lane] = carry;
 		} else if(wv == 1) {
 			const int t = T16[(lane >> 2) * TW + TW - 1];
@@ -677,6 +683,8 @@ int vp_sat_tiled(VpContext* ctx, int stream, const void* in, bool fused, int w, 
 	a.nTiles = (int)nt;
 	a.batch = batch;
 	a.zero = zero3;
+	a.spin_limit = ctx->tune.sat_spin_limit > 0 ? (uint32_t)ctx->tune.sat_spin_limit : SPIN_LIMIT;
+	a.drop_tile = ctx->tune.sat_debug_drop_tile;
 	const int rawRows = TH + 2 * o;
 	a.pitch = (rawRows * 2 * o + 3) & ~3; // halo array (dwords), 16-byte multiple
 	const size_t lds = sizeof(int) * ((size_t)rawRows * TW + a.pitch + TH * TW + NWAVES * TW + TW + TH + 8);
