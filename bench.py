@@ -543,7 +543,7 @@ def main():
     if args.plain_alloc:
         ctx.tune("placement_candidates", 0)
     elif not rehearse:
-        ctx.tune("placement_max_mib", -1)  # one rank per GPU and nobody else on it: the placement search may hold half of the free memory (default: a quarter of the device, with a reserve)
+        ctx.tune("placement_max_mib", -1)  # one rank per GPU and nobody else on it: the placement search may hold nine tenths of the free memory (default: a quarter of the device, with a reserve of an eighth)
     slab = ctx.frame_slab(params, B)
     flat, sat, matches, idx, counter = slab.torch_views()
     # what a rank contributes to the per-step gather: the COMPACT records (vp_records_compact: per frame counter[3], n and the n records a host loop

@@ -82,6 +82,14 @@ typedef struct __attribute__((packed)) {
 
 typedef struct VpContext VpContext;
 
+/* ABI revision of this header and of the library that was built from it: bumped whenever a struct the library WRITES into caller memory grows (VpPlacement
+ * gained `fast_gbs` in revision 2) or an entry point changes meaning.  A caller compiled against an older header checks vp_abi_version() == VP_ABI_VERSION
+ * before it hands the library arrays of such structs; vp_abi_sizeof names the structs' sizes as the library sees them ("VpPlacement", "VpFrameParams",
+ * "VpFrameBuffers", "VpCameraModel", "VpMatch", "VpStageTime"; 0 = unknown name). */
+#define VP_ABI_VERSION 3
+int vp_abi_version(void);
+size_t vp_abi_sizeof(const char* struct_name);
+
 /* ---- context / runtime: replaces OpenCL::OpenCL, wait, printRuntimes, clearEvents (opencl.h:72-112, opencl.cpp:34-101)
  * vp_ctx_create picks HIP device `device`, creates n_streams in-order streams (the reference uses one in-order queue,
  * opencl.cpp:48).  vp_ctx_adopt_stream wraps an existing hipStream_t (e.g. a PyTorch stream) as stream 0. */

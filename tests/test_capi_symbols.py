@@ -43,6 +43,19 @@ def test_libraries_export_every_declared_symbol(built):
             assert hasattr(hip, f), f
 
 
+def test_abi_version_and_struct_sizes(built):
+    """vp_abi_version / vp_abi_sizeof: a caller built against an older header can tell before it hands over arrays of a struct that has grown."""
+    capi = cases.vp.load_capi()
+    hip = capi.lib()
+    src = open(os.path.join(ROOT, "include", "vp_hip.h")).read()
+    assert hip.vp_abi_version() == int(re.search(r"#define VP_ABI_VERSION (\d+)", src).group(1))
+    hip.vp_abi_sizeof.restype = C.c_size_t
+    assert hip.vp_abi_sizeof(b"VpPlacement") == C.sizeof(capi.VpPlacement) == 24
+    assert hip.vp_abi_sizeof(b"VpFrameParams") == C.sizeof(capi.VpFrameParams)
+    assert hip.vp_abi_sizeof(b"VpFrameBuffers") == C.sizeof(capi.VpFrameBuffers)
+    assert hip.vp_abi_sizeof(b"VpMatch") == 22 and hip.vp_abi_sizeof(b"VpCameraModel") == 72 and hip.vp_abi_sizeof(b"nope") == 0
+
+
 def test_multi_gpu_library_exports_the_gather(built):
     """include/vp_multi.h (one process, N devices, RCCL all-gather of the per-step records) lives in libvp_multi.so; libvp_hip.so
     itself stays free of the RCCL dependency.  Without a GPU the constructor fails loudly.  (Loaded in a child process: RCCL brings the

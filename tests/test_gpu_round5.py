@@ -179,7 +179,7 @@ def test_placement_search_keeps_to_its_cap_and_reports_an_exhausted_budget(env):
         ctx.tune("placement_max_mib", 0)
         r = placed(2)
         assert all(2 <= x["candidates"] <= max(2, total // 4 // nbytes) for x in r), (r, total)
-        ctx.tune("placement_max_mib", -1)  # "the GPU is mine": half of the free memory, no reserve (bench.py, vp_feeds)
+        ctx.tune("placement_max_mib", -1)  # "the GPU is mine": nine tenths of the free memory, 1 GiB / 2 % reserve (bench.py, vp_feeds)
         r = placed(1)[0]
         assert r["raw_selected"] in (1, 2) and 1 <= r["candidates"] <= 64, r
         ctx.tune("placement_max_mib", 0)
@@ -265,7 +265,7 @@ def test_resampling_frame_pairs_and_groups_per_workgroup(env, port, shift):
 def test_resampling_groups_per_workgroup_on_the_unstaged_path(env, port):
     """A geometry whose 64 x 4-pixel tiles have footprint boxes too large for the LDS stage (one flat pixel spans four sensor cells: a box of ~130 x 20
     dwords) sends every workgroup of the default resampling kernel down its per-pixel path -- which must then cover ALL the 16-frame groups the workgroup
-    was given (two by default), not only the first: frames 16..36 of a 37-frame launch against the oracle."""
+    was given (four by default: resample_groups_per_wg 0 = automatic), not only the first: frames 16..36 of a 37-frame launch against the oracle."""
     capi, torch = env
     base = cfgs.T_MID
     fs = base.field_scale * 8.0

@@ -82,21 +82,25 @@ class _Fenced:
         setattr(self._f, k, v)
 
     def __call__(self, *a):
-        if _pending:
+        # Only entries that take (ctx, stream, ...) are fenced; which ones those are is decided by NAME (every entry of vp_hip.h except the ones listed in
+        # _NO_STREAM_ENTRIES has that shape), not by what the second argument happens to look like.  Tensors seen by _ptr() stay pending until a fence
+        # has actually been emitted for them: a call without a stream in between (vp_sync, vp_events_enable, ...) neither drops nor misuses them.
+        if _pending and self._f.__name__ not in _NO_STREAM_ENTRIES and len(a) >= 2 and isinstance(a[1], int):
+            import torch
             tensors = list(_pending)
-            _pending.clear()
-            # every stage entry is (ctx, stream, ...); entries without a stream take no tensors
-            if len(a) >= 2 and isinstance(a[1], int):
-                import torch
-                seen = set()
-                for t in tensors:
-                    sp = torch.cuda.current_stream(t.device).cuda_stream
-                    if (t.device.index, sp) in seen:
-                        continue
-                    seen.add((t.device.index, sp))
-                    rc = self._c.vp_stream_wait_for(a[0], a[1], C.c_void_p(sp))
-                    if rc != VP_OK:
-                        raise VpError(rc, self._c.vp_last_error().decode())
+            seen = set()
+            for t in tensors:
+                sp = torch.cuda.current_stream(t.device).cuda_stream
+                if (t.device.index, sp) in seen:
+                    continue
+                seen.add((t.device.index, sp))
+                if sp == 0 and t.device.index != _ctx_device.get(_handle_key(a[0]), t.device.index):
+                    # vp_stream_wait_for reads a NULL stream as the legacy stream of the CONTEXT's device: wrong for a tensor of another GPU
+                    raise VpError(-1, "FENCE_TORCH: tensor on cuda:%d sits on torch's default stream (handle 0) but the context is on another device; use a real torch stream" % t.device.index)
+                rc = self._c.vp_stream_wait_for(a[0], a[1], C.c_void_p(sp))
+                if rc != VP_OK:
+                    raise VpError(rc, self._c.vp_last_error().decode())
+            del _pending[:]
         return self._f(*a)
 
 
@@ -137,7 +141,18 @@ def lib():
 # then ordered before the call by a device-side event on the torch stream of the tensor's device.  bench.py and the tools leave it off (they synchronise
 # where they must).
 FENCE_TORCH = False
-_pending = []  # torch tensors _ptr() has seen since the last call went out (FENCE_TORCH only)
+_pending = []  # torch tensors _ptr() has seen and no fence has covered yet (FENCE_TORCH only)
+_ctx_device = {}  # context handle -> device ordinal (FENCE_TORCH's cross-device check)
+# entries of vp_hip.h whose second argument is NOT a stream index (no fence is emitted for them; pending tensors wait for the next stage call)
+_NO_STREAM_ENTRIES = frozenset({"vp_sync", "vp_ctx_create", "vp_ctx_adopt_stream", "vp_ctx_destroy", "vp_ctx_tune", "vp_events_enable", "vp_event_times", "vp_events_clear", "vp_frame_graph_stats",
+                                "vp_malloc_device", "vp_free_device", "vp_malloc_host", "vp_free_host", "vp_malloc_device_placed", "vp_buffer_create", "vp_buffer_destroy", "vp_buffer_size",
+                                "vp_image_acquire", "vp_image_release", "vp_image_info", "vp_frame_buffers_create", "vp_frame_buffers_placement", "vp_frame_buffers_destroy",
+                                "vp_device_name", "vp_device_count", "vp_abi_version", "vp_abi_sizeof", "vp_stream_wait_for", "vp_last_error", "vp_halo_strip_bytes", "vp_nv12_bytes",
+                                "vp_record_layout_compact", "vp_synth_frame", "vp_synth_camera", "vp_synth_truth"})
+
+
+def _handle_key(h):
+    return getattr(h, "value", h)
 
 
 def _ptr(x):
@@ -181,6 +196,7 @@ class Context:
             raise VpError(rc, self.l.vp_last_error().decode())
         self.h = h
         self.n_streams = 1 if stream_ptr is not None else n_streams
+        _ctx_device[h.value] = int(device)
 
     def close(self):
         if getattr(self, "h", None):

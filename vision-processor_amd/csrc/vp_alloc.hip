@@ -97,12 +97,14 @@ int vp_malloc_device_placed_impl(VpContext* ctx, size_t bytes, int count, void**
 	// (two searches that start together on one GPU -- two contexts, two processes -- then hold half of it at most between them).  Independently of
 	// that cap the loop below asks the device again before every candidate and stops once the memory free NOW, whoever took the rest, would fall
 	// under a reserve of an eighth of the device: somebody else's hipMalloc must not fail because this search is shopping.
-	// "placement_max_mib" = -1: the caller says the GPU is its own (bench.py, vp_feeds with one context per device): nine tenths of what is free, no reserve.
+	// "placement_max_mib" = -1: the caller says the GPU is its own (bench.py, vp_feeds with one context per device): nine tenths of what is free, and a small
+	// absolute reserve (1 GiB or 2 % of the device, whichever is more) for what the runtime, RCCL or a caching allocator on another thread may ask for meanwhile (ADVICE
+	// r05).  NO OTHER THREAD SHOULD ALLOCATE LARGE BLOCKS ON THE DEVICE while vp_frame_buffers_create / vp_malloc_device_placed runs in this mode.
 	size_t spend = std::min(free_b / 2, total_b / 4);
 	if(ctx->tune.placement_max_mib > 0) spend = std::min(free_b / 2, (size_t)ctx->tune.placement_max_mib << 20);
 	else if(ctx->tune.placement_max_mib < 0) spend = free_b - free_b / 10; // the GPU is the caller's own: nine tenths of what is free (at 256 cfg2 frames per step a candidate is 3.2 GB:
 	                                                                        // half of the memory was 44 candidates and ran out on boxes whose fast blocks are scarce)
-	const size_t reserve = ctx->tune.placement_max_mib < 0 ? 0 : total_b / 8;
+	const size_t reserve = ctx->tune.placement_max_mib < 0 ? std::max(size_t(1) << 30, total_b / 50) : total_b / 8;
 	bool met = false;
 	float fast_gbs = 0.f; // 0.70 x the read-stream rate of this device, measured on the first candidate
 	int n_fast = 0;

@@ -61,7 +61,7 @@ struct VpTuning {
 	int tail_emit_kernel = 1;      // walkers: records by a second launch from per-frame survivor queues (1, default) or inside the walker (0)
 	int sat_spin_limit = 0;        // single-pass SAT: polls a look-back wait may take before the launch gives up with VP_ERR_TIMEOUT (0 = 2^22, seconds); results do not depend on it
 	int sat_debug_drop_tile = -1;  // FAULT INJECTION for the tests (not result-neutral, by design): this tile's column carry is never published, see vp_sat_tiled.hip TiledArgs::drop_tile
-	int placement_max_mib = 0;     // vp_malloc_device_placed: MiB the search may hold at once (0 = half of the free device memory, at most a quarter of the device, and it stops while an eighth of the device is still free; -1 = the process owns the GPU: nine tenths of the free memory, no reserve)
+	int placement_max_mib = 0;     // vp_malloc_device_placed: MiB the search may hold at once (0 = half of the free device memory, at most a quarter of the device, and it stops while an eighth of the device is still free; -1 = the process owns the GPU: nine tenths of the free memory, a reserve of 1 GiB / 2 % of the device)
 	int placement_candidates = 96; // vp_malloc_device_placed / vp_frame_buffers_create: allocations probed at most per request (0 or 1: take what hipMalloc gives); 48 ran
 	                               // out twice in six fresh processes on a box whose fast blocks were scarce (profiles/r04_bench_spread.json); the bytes held stay capped
 };

@@ -101,6 +101,19 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 	delete ctx;
 }
 
+extern "C" int vp_abi_version(void) { return VP_ABI_VERSION; }
+extern "C" size_t vp_abi_sizeof(const char* name) {
+	if(!name) return 0;
+	const std::string n(name);
+	if(n == "VpPlacement") return sizeof(VpPlacement);
+	if(n == "VpFrameParams") return sizeof(VpFrameParams);
+	if(n == "VpFrameBuffers") return sizeof(VpFrameBuffers);
+	if(n == "VpCameraModel") return sizeof(VpCameraModel);
+	if(n == "VpMatch") return sizeof(VpMatch);
+	if(n == "VpStageTime") return sizeof(VpStageTime);
+	return 0;
+}
+
 extern "C" const char* vp_device_name(VpContext* ctx) { return ctx ? ctx->device_name.c_str() : ""; }
 
 extern "C" int vp_ctx_tune(VpContext* ctx, const char* key, int value) {

@@ -614,10 +614,13 @@ __global__ __launch_bounds__(256) void k_resample_staged(const uint8_t* __restri
 #define VP_RS_NSETS 2
 #endif
 #ifndef VP_RS_NSUB
-#define VP_RS_NSUB 16 // sub-groups of the written-out (FULL) path: groups_per_wg x RESAMPLE_FPT / FPS must equal it (4 groups of 16 frames)
+#define VP_RS_NSUB 16 // sub-groups of the written-out (FULL) path: groups_per_wg x RESAMPLE_FPT / FPS must be <= it (4 groups of 16 frames); a workgroup with fewer leaves the stream early
 #endif
 				constexpr int FPS = VP_RS_FPS;
 				static_assert(RESAMPLE_FPT % FPS == 0 && FPS % 2 == 0, "sub-groups of whole frame pairs");
+				// the -D overrides were a sweep (profiles/r05_resample_lds_bound.json); what the pair stream supports: a set is requested NSETS - 1 sub-groups ahead of
+				// its use and must not be the one in use, and a sub-group must span at least two pairs for the request to go out ahead of its first store
+				static_assert(VP_RS_NSETS >= 2 && VP_RS_NSETS <= VP_RS_NSUB && FPS >= 4, "unsupported VP_RS_FPS / VP_RS_NSETS / VP_RS_NSUB combination");
 				float* F = reinterpret_cast<float*>(&stage[0][0]); // [2][2048]: per box row [plane A: (2 wdw + 4) cells x (frame f, frame f + 1) | plane B likewise]
 				const int PL = 4 * wdw + 8, RP = 2 * PL;            // floats per plane of a box row, per box row
 				const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.y);

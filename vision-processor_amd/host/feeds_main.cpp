@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
 
 	VpContext* ctx = nullptr;
 	CK(vp_ctx_create(0, 2, &ctx));
-	CK(vp_ctx_tune(ctx, "placement_max_mib", -1)); // the program owns its GPU: the placement search may hold half of the free memory
+	CK(vp_ctx_tune(ctx, "placement_max_mib", -1)); // the program owns its GPU: the placement search may hold nine tenths of the free memory
 	const size_t rawBytes = (size_t)4 * qw * qh;
 	// synthetic feeds, resident in HBM before the clock starts
 	uint8_t* dRaw = nullptr;

@@ -117,7 +117,7 @@ int vp_feeds_run_multi(const MultiOptions& o) {
 				Dev& d = dev[g];
 				d.g = g;
 				CK(vp_ctx_create(devs[g], 2, &d.ctx));
-				if(!o.same_device) CK(vp_ctx_tune(d.ctx, "placement_max_mib", -1)); // one context per device, the program owns its GPUs: the search may hold half of the free memory
+				if(!o.same_device) CK(vp_ctx_tune(d.ctx, "placement_max_mib", -1)); // one context per device, the program owns its GPUs: the search may hold nine tenths of the free memory
 				if(o.same_device) CK(vp_ctx_tune(d.ctx, "placement_candidates", 0)); // N contexts searching one device's memory at once would starve each other; the rehearsal does not care where its blocks land
 				ctxs[g] = d.ctx;
 				CK(vp_malloc_device(d.ctx, rawBytes * feeds, (void**)&d.dRaw));
