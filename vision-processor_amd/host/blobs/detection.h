@@ -161,6 +161,35 @@ struct BotHypothesis { // blobs/hypothesis.h:44-91: base + Detection / Tracked v
 };
 
 // hypothesis.cpp
+// Memo of calcPos's pairwise terms (hypothesis.cpp:158-168) over ONE neighbourhood of blobs.  A frame builds ~1 600 robot hypotheses from ~135 blobs, and each one
+// evaluates atan2_fast + sinf + cosf for its ten blob pairs -- three quarters of the CPU stage's time (tools/dbg/detect_prof.cpp) -- yet the hypotheses of one centre blob
+// (main.cpp:43-83) or one tracked robot (:85-139) keep recombining the same few blobs: the term of blob i in pattern slot a and blob j in slot b depends on nothing else.
+// The memo hands back the SAME float values the direct evaluation produces, and calcPos adds them in the same order: bit-identical results.
+// Blobs are named by small local ids (0 .. n-1) the caller assigns; begin(n) forgets everything.
+class PairTerms {
+public:
+	void begin(int nBlobs);
+	// sin / cos of atan2_fast(pos_j - pos_i) - patternAnglesb2b[b * 5 + a] for blob id i in slot a and blob id j in slot b (a < b)
+	void term(int i, int j, int a, int b, const Match* mi, const Match* mj, float& s, float& c) {
+		const size_t pair = (size_t)i * n + j, t = pair * 10 + (size_t)(a * (9 - a) / 2 + b - a - 1); // (a, b), a < b < 5, in lexicographic order: 0 .. 9
+		if(termGen[t] != gen) fill(pair, t, a, b, mi, mj);
+		s = sc[2 * t];
+		c = sc[2 * t + 1];
+	}
+
+private:
+	void fill(size_t pair, size_t t, int a, int b, const Match* mi, const Match* mj);
+	int n = 0;
+	uint32_t gen = 0;
+	std::vector<uint32_t> angleGen, termGen; // entry valid iff == gen
+	std::vector<float> angle;                // [i * n + j]
+	std::vector<float> sc;                   // [((i * n + j) * 10 + slotPair) * 2]
+};
+// hypothesis.cpp:97-105 (the shared base of both hypothesis kinds) with the memo; ids[k] names blobs[k] (ignored where blobs[k] is null)
+BotHypothesis makeBotHypothesisBase(PairTerms& terms, const Match* const blobs[5], const int ids[5]);
+void calcBotId(const BlobResources& r, BotHypothesis& bot); // :216-228: only reads the blobs' colours and r's colour model, only writes bot.botId
+BotHypothesis makeTrackedBotHypothesis(const BlobResources& r, const TrackingState& tracked, const Vec3f& trackedPosition, PairTerms& terms, const Match* const blobs[5], const int ids[5]);
+
 BallHypothesis makeBallHypothesis(const BlobResources& r, const Match* blob);                                                   // :61-63
 void recalcPostColorCalib(const BlobResources& r, BallHypothesis& ball);                                                       // :65-68
 void recalcPostColorCalib(const BlobResources& r, BotHypothesis& bot);                                                         // :212-214, :252-255

@@ -35,6 +35,7 @@ bool closerThanCamEdgeDistance(const BlobResources& r, const Vec2f& pos, const V
 void generateAngleSortedBotHypotheses(const BlobResources& r, std::vector<BotHypothesis>& bots, std::vector<Match>& matches, KDTree& blobs) { // main.cpp:43-83
 	std::vector<Match*> botBlobs;
 	std::vector<std::pair<float, Match*>> keyed;
+	PairTerms terms; // calcPos's pairwise terms, shared by the hypotheses of one centre blob (detection.h)
 	for(int i = 0; i < blobs.getSize(); i++) {
 		Match& blob = matches[i];
 		botBlobs.clear();
@@ -52,11 +53,16 @@ void generateAngleSortedBotHypotheses(const BlobResources& r, std::vector<BotHyp
 		bool haveBest = false;
 		BotHypothesis bestBot;
 		const int size = (int)botBlobs.size();
+		terms.begin(size + 1); // local ids: 0 = the centre blob, k + 1 = botBlobs[k]
 		for(int a = 0; a < size; a++)
 			for(int b = a + 1; b < a + size - 2; b++)
 				for(int c = b + 1; c < a + size - 1; c++)
 					for(int d = c + 1; d < a + size; d++) {
-						BotHypothesis bot = makeDetectionBotHypothesis(r, &blob, botBlobs[a], botBlobs[b % size], botBlobs[c % size], botBlobs[d % size]);
+						// DetectionBotHypothesis (hypothesis.cpp:208-210) = the base + calcBotId.  calcBotId neither reads nor writes the score the comparison below
+						// looks at, and only the winner leaves this loop: its k-means runs once per centre blob, below, instead of once per candidate
+						const Match* const five[5] = {&blob, botBlobs[a], botBlobs[b % size], botBlobs[c % size], botBlobs[d % size]};
+						const int ids[5] = {0, a + 1, b % size + 1, c % size + 1, d % size + 1};
+						const BotHypothesis bot = makeBotHypothesisBase(terms, five, ids);
 						if(bot.score > bestBotScore) {
 							bestBotScore = bot.score;
 							bestBot = bot;
@@ -65,7 +71,10 @@ void generateAngleSortedBotHypotheses(const BlobResources& r, std::vector<BotHyp
 					}
 		// The reference appends bestBot even when no candidate scored above 0 (a null pointer, dereferenced by the next filter:
 		// main.cpp:82,143-145).  That needs a NaN or infinite offset; here such a centre blob contributes nothing.
-		if(haveBest) bots.push_back(bestBot);
+		if(haveBest) {
+			calcBotId(r, bestBot);
+			bots.push_back(bestBot);
+		}
 	}
 }
 
@@ -73,6 +82,9 @@ void generateRadiusSearchTrackedBotHypotheses(const BlobResources& r, std::vecto
 	(void)matches;
 	const CameraModel& model = r.perspective->model;
 	std::vector<Match*> botBlobs[5];
+	std::vector<int> blobIds[5];   // local id of every entry of botBlobs[i] (the same blob may lie within reach of several pattern positions)
+	std::vector<Match*> distinct;
+	PairTerms terms;
 	for(const auto& camTracked : r.trackedObjects) {
 		for(const TrackingState& tracked : camTracked.second) {
 			if(tracked.id == -1) continue;
@@ -94,19 +106,36 @@ void generateRadiusSearchTrackedBotHypotheses(const BlobResources& r, std::vecto
 				blobs.rangeSearch(botBlobs[i], {trackedPosition.x + rp.x, trackedPosition.y + rp.y}, blobSearchRadius);
 			}
 
+			distinct.clear();
+			for(int i = 0; i < 5; i++) {
+				blobIds[i].assign(botBlobs[i].size(), 0);
+				for(size_t k = 1; k < botBlobs[i].size(); k++) { // [0] is the "no blob at this position" entry
+					const auto it = std::find(distinct.begin(), distinct.end(), botBlobs[i][k]);
+					blobIds[i][k] = (int)(it - distinct.begin());
+					if(it == distinct.end()) distinct.push_back(botBlobs[i][k]);
+				}
+			}
+			terms.begin((int)distinct.size());
+
 			float bestBotScore = 0.0f;
 			bool haveBest = false;
 			BotHypothesis bestBot;
-			for(Match* a : botBlobs[0])
-				for(Match* b : botBlobs[1]) {
+			for(size_t ia = 0; ia < botBlobs[0].size(); ia++)
+				for(size_t ib = 0; ib < botBlobs[1].size(); ib++) {
+					Match *const a = botBlobs[0][ia], *const b = botBlobs[1][ib];
 					if(b != nullptr && a == b) continue;
-					for(Match* c : botBlobs[2]) {
+					for(size_t ic = 0; ic < botBlobs[2].size(); ic++) {
+						Match* const c = botBlobs[2][ic];
 						if(c != nullptr && (a == c || b == c)) continue;
-						for(Match* d : botBlobs[3]) {
+						for(size_t id = 0; id < botBlobs[3].size(); id++) {
+							Match* const d = botBlobs[3][id];
 							if(d != nullptr && (a == d || b == d || c == d)) continue;
-							for(Match* e : botBlobs[4]) {
+							for(size_t ie = 0; ie < botBlobs[4].size(); ie++) {
+								Match* const e = botBlobs[4][ie];
 								if(e != nullptr && (a == e || b == e || c == e || d == e)) continue;
-								BotHypothesis bot = makeTrackedBotHypothesis(r, tracked, trackedPosition, a, b, c, d, e);
+								const Match* const five[5] = {a, b, c, d, e};
+								const int ids[5] = {blobIds[0][ia], blobIds[1][ib], blobIds[2][ic], blobIds[3][id], blobIds[4][ie]};
+								BotHypothesis bot = makeTrackedBotHypothesis(r, tracked, trackedPosition, terms, five, ids);
 								if(bot.score > bestBotScore) {
 									bestBotScore = bot.score;
 									bestBot = bot;

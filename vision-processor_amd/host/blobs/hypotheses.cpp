@@ -52,16 +52,23 @@ void calcColorScore(const BlobResources& r, BallHypothesis& ball) { // :82-94
 	ball.score *= 1 - (float)orange / (float)falseOrange;
 }
 
-Rot2 calcPos(BotHypothesis& bot) { // :155-191; returns Rotation2Df(orientation), which calcOffsetScore builds again in the reference (same value)
+Rot2 calcPos(BotHypothesis& bot, PairTerms* terms, const int* ids) { // :155-191; returns Rotation2Df(orientation), which calcOffsetScore builds again in the reference (same value)
 	float oSin = 0, oCos = 0;
 	for(int a = 0; a < 5; a++) {
 		if(bot.blobs[a] == nullptr) continue;
 		for(int b = a + 1; b < 5; b++) {
 			if(bot.blobs[b] == nullptr) continue;
-			const Vec2f diff{bot.blobs[b]->pos.x - bot.blobs[a]->pos.x, bot.blobs[b]->pos.y - bot.blobs[a]->pos.y};
-			const float angleDelta = atan2_fast(diff.y, diff.x) - patternAnglesb2b[b * 5 + a];
-			oSin += sinf(angleDelta);
-			oCos += cosf(angleDelta);
+			float s, c;
+			if(terms) {
+				terms->term(ids[a], ids[b], a, b, bot.blobs[a], bot.blobs[b], s, c);
+			} else {
+				const Vec2f diff{bot.blobs[b]->pos.x - bot.blobs[a]->pos.x, bot.blobs[b]->pos.y - bot.blobs[a]->pos.y};
+				const float angleDelta = atan2_fast(diff.y, diff.x) - patternAnglesb2b[b * 5 + a];
+				s = sinf(angleDelta);
+				c = cosf(angleDelta);
+			}
+			oSin += s;
+			oCos += c;
 		}
 	}
 	if(bot.blobAmount < 1) return Rot2(bot.orientation);
@@ -91,17 +98,48 @@ void calcOffsetScore(BotHypothesis& bot, const Rot2& rotation) { // :193-205
 	bot.score = bot.offsetScore;
 }
 
-BotHypothesis makeBase(const Match* a, const Match* b, const Match* c, const Match* d, const Match* e) { // :97-105
+BotHypothesis makeBase(const Match* a, const Match* b, const Match* c, const Match* d, const Match* e, PairTerms* terms = nullptr, const int* ids = nullptr) { // :97-105
 	BotHypothesis bot;
 	const Match* in[5] = {a, b, c, d, e};
 	for(int i = 0; i < 5; i++) {
 		bot.blobs[i] = in[i];
 		if(in[i] != nullptr) bot.blobAmount++;
 	}
-	const Rot2 rotation = calcPos(bot);
+	const Rot2 rotation = calcPos(bot, terms, ids);
 	calcOffsetScore(bot, rotation);
 	return bot;
 }
+
+} // namespace
+
+void PairTerms::begin(int nBlobs) {
+	n = nBlobs;
+	if(++gen == 0) { // the stamps wrapped: forget them all
+		std::fill(angleGen.begin(), angleGen.end(), 0u);
+		std::fill(termGen.begin(), termGen.end(), 0u);
+		gen = 1;
+	}
+	const size_t pairs = (size_t)n * n;
+	if(angleGen.size() < pairs) {
+		angleGen.assign(pairs, 0u);
+		angle.resize(pairs);
+		termGen.assign(pairs * 10, 0u);
+		sc.resize(pairs * 20);
+	}
+}
+
+void PairTerms::fill(size_t pair, size_t t, int a, int b, const Match* mi, const Match* mj) {
+	if(angleGen[pair] != gen) {
+		angle[pair] = atan2_fast(mj->pos.y - mi->pos.y, mj->pos.x - mi->pos.x);
+		angleGen[pair] = gen;
+	}
+	const float angleDelta = angle[pair] - patternAnglesb2b[b * 5 + a];
+	sc[2 * t] = sinf(angleDelta);
+	sc[2 * t + 1] = cosf(angleDelta);
+	termGen[t] = gen;
+}
+
+BotHypothesis makeBotHypothesisBase(PairTerms& terms, const Match* const blobs[5], const int ids[5]) { return makeBase(blobs[0], blobs[1], blobs[2], blobs[3], blobs[4], &terms, ids); }
 
 void calcBotId(const BlobResources& r, BotHypothesis& bot) { // :216-228
 	Vec3i green = r.green, pink = r.pink;
@@ -111,6 +149,8 @@ void calcBotId(const BlobResources& r, BotHypothesis& bot) { // :216-228
 	const int team = sqDiff(bot.blobs[0]->color, r.blue) < sqDiff(bot.blobs[0]->color, r.yellow) ? 16 : 0;
 	bot.botId = team + patternLUT[(isGreen(1) << 3) + (isGreen(2) << 2) + (isGreen(3) << 1) + isGreen(4)];
 }
+
+namespace {
 
 void calcTrackingScore(const BlobResources& r, BotHypothesis& bot) { // :257-282
 	if(bot.blobAmount < 2) {
@@ -178,9 +218,18 @@ BotHypothesis makeDetectionBotHypothesis(const BlobResources& r, const Match* a,
 	return bot;
 }
 
+static BotHypothesis finishTracked(const BlobResources& r, const TrackingState& tracked, const Vec3f& trackedPosition, BotHypothesis bot);
+
 BotHypothesis makeTrackedBotHypothesis(const BlobResources& r, const TrackingState& tracked, const Vec3f& trackedPosition, const Match* a, const Match* b, const Match* c,
 		const Match* d, const Match* e) {
-	BotHypothesis bot = makeBase(a, b, c, d, e);
+	return finishTracked(r, tracked, trackedPosition, makeBase(a, b, c, d, e));
+}
+
+BotHypothesis makeTrackedBotHypothesis(const BlobResources& r, const TrackingState& tracked, const Vec3f& trackedPosition, PairTerms& terms, const Match* const blobs[5], const int ids[5]) {
+	return finishTracked(r, tracked, trackedPosition, makeBase(blobs[0], blobs[1], blobs[2], blobs[3], blobs[4], &terms, ids));
+}
+
+static BotHypothesis finishTracked(const BlobResources& r, const TrackingState& tracked, const Vec3f& trackedPosition, BotHypothesis bot) { // hypothesis.cpp:241-250
 	bot.tracked = true;
 	bot.trackedScore = tracked.confidence;
 	bot.trackedPosition = trackedPosition;
