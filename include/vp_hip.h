@@ -97,6 +97,9 @@ int vp_ctx_create(int device, int n_streams, VpContext** out);
 int vp_ctx_adopt_stream(int device, void* hip_stream, VpContext** out);
 void vp_ctx_destroy(VpContext* ctx);
 int vp_sync(VpContext* ctx, int stream);              /* OpenCL::wait (opencl.cpp:87-92); stream < 0 = all */
+/* clFlush: makes sure everything enqueued on the stream so far has been handed to the device, without waiting for it (hipStreamQuery).  Returns VP_OK
+ * whether or not the work has finished; stream < 0 = all. */
+int vp_flush(VpContext* ctx, int stream);
 /* Ordering against streams the library does not own -- the device-side counterpart of the cl::Event every OpenCL::run returns (opencl.h:76-86), which a
  * cl::EnqueueArgs can wait for; the reference itself has one in-order queue (opencl.cpp:48) plus map / unmap from its RTP and snapshot threads.  A context's own streams are
  * non-blocking, so a buffer the caller fills on another stream (hipMemcpyAsync, a kernel, torch) is NOT ordered before a vp_* call on a library stream.
@@ -351,6 +354,15 @@ int vp_frame(VpContext* ctx, int stream, const VpFrameParams* params, const uint
  * (a multiple of 256) and the slot size / offsets.  This is what vp_feeds reads back and what its multi-GPU gather carries (include/vp_multi.h). */
 size_t vp_record_layout_compact(int batch, int cap, size_t* slot_bytes, size_t* off_matches, size_t* off_idx);
 int vp_records_compact(VpContext* ctx, int stream, const int32_t* counter, const VpMatch* matches, const uint32_t* idx, int batch, int max_matches, int cap, uint8_t* out);
+/* The same with a completion WORD for host loops that read the records back (main.cpp:297-301 maps and waits): `out` and `done_word` live in pinned host memory
+ * (vp_malloc_host; device-visible), the kernel stores the slots there itself and its last workgroup then stores `done_value` into *done_word at system scope.
+ * The host waits with vp_wait_word (a spin on its own memory: VP_OK, or VP_ERR_TIMEOUT after timeout_s seconds, 0 = wait for ever) instead of vp_sync: the
+ * completion reaches it without a marker packet and an interrupt -- on an MI355X whose queues have run dry that round trip costs ~0.6 ms (the device has to be
+ * woken to answer; profiles/r06_vp_feeds.jsonl), and ~10 us per step otherwise.  Use a value that changes from step to step (a step counter).  An error raised
+ * by the stream's kernels is still reported by vp_sync only. */
+int vp_records_compact_signal(VpContext* ctx, int stream, const int32_t* counter, const VpMatch* matches, const uint32_t* idx, int batch, int max_matches, int cap, uint8_t* out,
+		uint32_t* done_word, uint32_t done_value);
+int vp_wait_word(const volatile uint32_t* word, uint32_t value, double timeout_s);
 
 /* ---- synthetic input (libvp_host.so; host-side, no GPU) --------------------------------------------------------------
  * Deterministic test/benchmark frames; not part of the reference. */

@@ -1,5 +1,6 @@
 """GPU tests added in round 6, all through the C ABI.
 
+  * vp_records_compact_signal / vp_wait_word / vp_flush: the read-back of main.cpp:297-301 without a copy command or a stream synchronisation on the way.
   * the library's one recovery path, executed: a look-back wait of the single-pass SAT that never ends -> bounded launch -> VP_ERR_TIMEOUT from vp_sync
     -> the stream's next launch resets the carry state and is correct again; other streams of the context never notice.
 """
@@ -99,5 +100,59 @@ def test_a_lookback_wait_that_never_ends_is_bounded_reported_and_recovered_from(
             assert torch.equal(b0.sat, good_sat)
             for f in range(B): check(capi, b0, f, want[f], mm)
         ctx.sync()
+    finally:
+        ctx.close()
+
+
+def test_records_reach_the_host_through_a_completion_word(env, port):
+    """vp_records_compact_signal stores the compact slots straight into pinned host memory and its last workgroup then stores a step number into a completion
+    word; the host learns that the records are readable by polling that word (vp_wait_word) -- no copy command, no vp_sync between the launch and the read.
+    Three steps with different frames on one stream, each waited for by its own value; the slots must be byte for byte what vp_records_compact + a blocking copy
+    deliver, and what the oracle says.  vp_flush (clFlush) is a no-op for results and must not fail on a busy stream; a word that never comes is a
+    VP_ERR_TIMEOUT, not a hang."""
+    import ctypes as C
+    capi, torch = env
+    cfg, mm, B, cap = cfgs.T_MID, cfgs.T_MID.max_matches, 5, 192
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        capi.lib().vp_record_layout_compact.restype = C.c_size_t
+        slot, offm, offi = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        total = capi.lib().vp_record_layout_compact(B, cap, C.byref(slot), C.byref(offm), C.byref(offi))
+        h_slots = ctx.malloc_host(total)
+        h_word = ctx.malloc_host(64)
+        word = (C.c_uint32 * 16).from_address(h_word)
+        word[0] = 0
+        host = np.ctypeslib.as_array((C.c_uint8 * total).from_address(h_slots))
+        p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+        b = Buffers(torch, cfg, B, mm)
+        d_slots = torch.zeros(total, dtype=torch.uint8, device="cuda")
+        for step in range(1, 4):
+            raws = [cfg.synth(9300 + 10 * step + i) for i in range(B)]
+            d_raw = torch.from_numpy(np.stack(raws)).cuda()
+            host[:] = 0xEE
+            ctx.frame(p, d_raw, B, stream=0, **b.kw())
+            ctx.records_compact_signal(b.cnt, b.m, b.idx, B, mm, cap, h_slots, h_word, step)
+            ctx.flush(0)
+            ctx.wait_word(h_word, step, 20.0)          # no vp_sync: the word is the only thing the host waits for
+            got = host.copy()
+            ctx.sync(0)
+            ctx.records_compact(b.cnt, b.m, b.idx, B, mm, cap, d_slots)
+            ctx.sync(0)
+            want = d_slots.cpu().numpy()
+            for f in range(B):
+                wm, widx, wcnt = oracle_frame(port, cfg, raws[f], mm)
+                s0 = f * slot.value
+                head = got[s0:s0 + 16].view(np.int32)
+                n = min(int(wcnt[0]), mm, cap)
+                assert head[:3].tolist() == wcnt.tolist() and head[3] == n and n >= 20
+                # the bytes of the slot that are defined (header, n records, n indices) equal the device-block form
+                assert np.array_equal(got[s0:s0 + 16 + 22 * n], want[s0:s0 + 16 + 22 * n])
+                assert np.array_equal(got[s0 + offi.value:s0 + offi.value + 4 * n], want[s0 + offi.value:s0 + offi.value + 4 * n])
+                assert got[s0 + 16:s0 + 16 + 22 * n].tobytes() == wm[:n].tobytes() and np.array_equal(got[s0 + offi.value:s0 + offi.value + 4 * n].view(np.uint32), widx[:n])
+        with pytest.raises(capi.VpError) as e:
+            ctx.wait_word(h_word, 99, 0.05)
+        assert e.value.code == -4
+        ctx.free_host(h_slots)
+        ctx.free_host(h_word)
     finally:
         ctx.close()

@@ -144,7 +144,7 @@ FENCE_TORCH = False
 _pending = []  # torch tensors _ptr() has seen and no fence has covered yet (FENCE_TORCH only)
 _ctx_device = {}  # context handle -> device ordinal (FENCE_TORCH's cross-device check)
 # entries of vp_hip.h whose second argument is NOT a stream index (no fence is emitted for them; pending tensors wait for the next stage call)
-_NO_STREAM_ENTRIES = frozenset({"vp_sync", "vp_ctx_create", "vp_ctx_adopt_stream", "vp_ctx_destroy", "vp_ctx_tune", "vp_events_enable", "vp_event_times", "vp_events_clear", "vp_frame_graph_stats",
+_NO_STREAM_ENTRIES = frozenset({"vp_sync", "vp_flush", "vp_wait_word", "vp_ctx_create", "vp_ctx_adopt_stream", "vp_ctx_destroy", "vp_ctx_tune", "vp_events_enable", "vp_event_times", "vp_events_clear", "vp_frame_graph_stats",
                                 "vp_malloc_device", "vp_free_device", "vp_malloc_host", "vp_free_host", "vp_malloc_device_placed", "vp_buffer_create", "vp_buffer_destroy", "vp_buffer_size",
                                 "vp_image_acquire", "vp_image_release", "vp_image_info", "vp_frame_buffers_create", "vp_frame_buffers_placement", "vp_frame_buffers_destroy",
                                 "vp_device_name", "vp_device_count", "vp_abi_version", "vp_abi_sizeof", "vp_stream_wait_for", "vp_last_error", "vp_halo_strip_bytes", "vp_nv12_bytes",
@@ -363,6 +363,25 @@ class Context:
     def records_compact(self, counter, matches, idx, batch, max_matches, cap, out, stream=0):
         """vp_records_compact: counter[3], n and the n records of every frame into one slot per frame (what a host loop reads back / a gather carries)."""
         self._ck(self.l.vp_records_compact(self.h, stream, _ptr(counter), _ptr(matches), _ptr(idx), int(batch), int(max_matches), int(cap), _ptr(out)))
+
+    def records_compact_signal(self, counter, matches, idx, batch, max_matches, cap, out_host_ptr, done_word_ptr, done_value, stream=0):
+        """vp_records_compact_signal: the slots go straight into pinned host memory (malloc_host) and the last workgroup stores done_value into the completion word."""
+        self._ck(self.l.vp_records_compact_signal(self.h, stream, _ptr(counter), _ptr(matches), _ptr(idx), int(batch), int(max_matches), int(cap), C.c_void_p(out_host_ptr),
+                                                  C.c_void_p(done_word_ptr), C.c_uint32(done_value)))
+
+    def wait_word(self, word_ptr, value, timeout_s=10.0):
+        self._ck(self.l.vp_wait_word(C.c_void_p(word_ptr), C.c_uint32(value), C.c_double(timeout_s)))
+
+    def flush(self, stream=-1):
+        self._ck(self.l.vp_flush(self.h, int(stream)))
+
+    def malloc_host(self, nbytes) -> int:
+        p = C.c_void_p()
+        self._ck(self.l.vp_malloc_host(self.h, C.c_size_t(nbytes), C.byref(p)))
+        return p.value
+
+    def free_host(self, hptr):
+        self._ck(self.l.vp_free_host(self.h, C.c_void_p(hptr)))
 
     def frame_slab(self, params: VpFrameParams, batch, views=0) -> "FrameSlab":
         return FrameSlab(self, params, batch, views)

@@ -95,6 +95,7 @@ struct VpContext {
 	std::vector<VpFrameGraph> graphs;
 	int64_t graph_stats[4] = {};                   // captures, replays, refused captures, dropped graphs (vp_frame_graph_stats)
 	int* host_flag[VP_MAX_STREAMS] = {};           // pinned, device-mapped word the SAT kernel raises on a look-back timeout
+	uint32_t* compact_arrived[VP_MAX_STREAMS] = {}; // vp_records_compact_signal: arrival counter of the launch's workgroups (device, self-cleaning)
 	std::string device_name;
 	int cu_count = 0;
 	VpTuning tune;

@@ -86,6 +86,7 @@ extern "C" void vp_ctx_destroy(VpContext* ctx) {
 		for(int k = 0; k < VP_WS_SLOTS; k++)
 			if(ctx->ws[k][i].ptr) (void)hipFree(ctx->ws[k][i].ptr);
 		if(ctx->host_flag[i]) (void)hipHostFree(ctx->host_flag[i]);
+		if(ctx->compact_arrived[i]) (void)hipFree(ctx->compact_arrived[i]);
 		if(ctx->own_streams) (void)hipStreamDestroy(ctx->streams[i]);
 	}
 	for(auto& e : ctx->events) {
@@ -231,6 +232,22 @@ extern "C" int vp_sync(VpContext* ctx, int stream) {
 	VP_TRY(vp_check_ctx(ctx, stream));
 	VP_CHECK_HIP(hipStreamSynchronize(ctx->streams[stream]));
 	return vp_check_timeout(ctx, stream);
+}
+
+extern "C" int vp_flush(VpContext* ctx, int stream) {
+	VP_REQUIRE(ctx, "null context");
+	VP_CHECK_HIP(hipSetDevice(ctx->device));
+	for(int i = 0; i < ctx->n_streams; i++) {
+		if(stream >= 0 && i != stream) continue;
+		const hipError_t e = hipStreamQuery(ctx->streams[i]);
+		if(e != hipSuccess && e != hipErrorNotReady) {
+			vp_set_error("hipStreamQuery failed: %s", hipGetErrorString(e));
+			return VP_ERR_HIP;
+		}
+		(void)hipGetLastError(); // hipErrorNotReady is the expected answer, not an error to leave behind
+	}
+	if(stream >= ctx->n_streams) return vp_check_ctx(ctx, stream);
+	return VP_OK;
 }
 
 int vp_workspace(VpContext* ctx, int stream, int slot, size_t bytes, void** out, bool* grew) {

@@ -94,6 +94,8 @@ int main(int argc, char** argv) {
 	}
 	const int feeds = argc > 1 ? atoi(argv[1]) : 128, steps = argc > 2 ? atoi(argv[2]) : 20, warmup = argc > 3 ? atoi(argv[3]) : 3;
 	const int threads = argc > 4 ? atoi(argv[4]) : 16, detect = argc > 5 ? atoi(argv[5]) : 1;
+	const int stageEvents = argc > 7 ? atoi(argv[7]) : 0; // 1: per-stage hipEvent times of the timed steps on stderr (printRuntimes)
+	const int readback = argc > 6 ? atoi(argv[6]) : 2; // 2: the compact kernel stores the pinned host block AND a completion word the host polls (no vp_sync on the way); 1: host block, vp_sync; 0: device block + hipMemcpyAsync, vp_sync
 	if(feeds < 1 || steps < 1 || warmup < 0 || threads < 1) {
 		fprintf(stderr, "usage: vp_feeds [feeds] [steps] [warmup] [host_threads] [detect 0|1]\n");
 		return 2;
@@ -133,6 +135,9 @@ int main(int argc, char** argv) {
 		CK(vp_malloc_device(ctx, compactBytes, (void**)&dSlots[s]));
 		CK(vp_malloc_host(ctx, compactBytes, &hSlots[s]));
 	}
+	uint32_t* doneWord = nullptr; // one completion word per buffer set, a cache line apart
+	CK(vp_malloc_host(ctx, 256, (void**)&doneWord));
+	memset(doneWord, 0, 256);
 	// one detector per feed: own colour model, own tracker (main.cpp runs one process per camera)
 	std::vector<VphDetector*> detectors;
 	const float calib[11] = {p.model.f, p.model.p[0], p.model.p[1], p.model.d, -1.f, 0.f, 0.f, 0.f, -p.model.c[0], p.model.c[1], p.model.c[2]}; // nadir: t = R (-pos)
@@ -157,7 +162,8 @@ int main(int argc, char** argv) {
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	auto cpuStage = [&](int s, int frameNo) { // the read-back of step `frameNo` sits in host set s
 		const auto w0 = now();
-		CK(vp_sync(ctx, s));
+		if(readback == 2) CK(vp_wait_word(doneWord + 16 * s, (uint32_t)frameNo, 30.0)); // step frameNo - 1 stored frameNo (launch: k + 1)
+		else CK(vp_sync(ctx, s));
 		const auto w1 = now();
 		waitMs += ms(w0, w1);
 		const uint8_t* slots = static_cast<const uint8_t*>(hSlots[s]);
@@ -183,8 +189,15 @@ int main(int argc, char** argv) {
 		const auto l0 = now();
 		const int s = k & 1;
 		CK(vp_frame(ctx, s, &p, dRaw, feeds, &buf[s]));
-		CK(vp_records_compact(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, dSlots[s]));
-		CK(vp_copy_d2h(ctx, s, hSlots[s], dSlots[s], compactBytes));
+		// the compact block is 1.3 MB per 256 feeds: the kernel stores it straight into the pinned host block (hipHostMalloc memory is device-visible), which
+		// becomes readable with the stream's completion; as a separate copy command behind the kernel it added 0.65 ms of waiting per step
+		// (profiles/r06_vp_feeds.jsonl)
+		if(readback == 2) CK(vp_records_compact_signal(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, static_cast<uint8_t*>(hSlots[s]), doneWord + 16 * s, (uint32_t)(k + 1)));
+		else if(readback) CK(vp_records_compact(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, static_cast<uint8_t*>(hSlots[s])));
+		else {
+			CK(vp_records_compact(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, dSlots[s]));
+			CK(vp_copy_d2h(ctx, s, hSlots[s], dSlots[s], compactBytes));
+		}
 		launchMs += ms(l0, now());
 	};
 
@@ -197,6 +210,7 @@ int main(int argc, char** argv) {
 	CK(vp_sync(ctx, -1));
 	blobs = packetBytes = 0;
 	waitMs = stageMs = launchMs = 0;
+	if(stageEvents) CK(vp_events_enable(ctx, 1));
 	const auto t0 = std::chrono::steady_clock::now();
 	for(int j = 0; j < steps; j++, k++) {
 		launch(k);
@@ -206,6 +220,14 @@ int main(int argc, char** argv) {
 	CK(vp_sync(ctx, -1));
 	const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
+	if(stageEvents) {
+		std::vector<VpStageTime> st(4096);
+		const int n = vp_event_times(ctx, st.data(), (int)st.size());
+		double sum = 0;
+		for(int i = 0; i < n; i++) sum += st[i].ms;
+		fprintf(stderr, "stage events: %d launches, %.3f ms of GPU time per step\n", n, sum / steps);
+		for(int i = 0; i < n && i < 12; i++) fprintf(stderr, "  %-40s %.3f ms\n", st[i].stage, st[i].ms);
+	}
 	int robotsSeen = 0, ballsSeen = 0;
 	if(detect)
 		for(VphDetector* d : detectors) {
@@ -214,7 +236,7 @@ int main(int argc, char** argv) {
 			robotsSeen += h.n_robots_yellow + h.n_robots_blue;
 			ballsSeen += h.n_balls;
 		}
-	printf("{\"program\": \"vp_feeds\", \"feeds\": %d, \"steps\": %d, \"host_threads\": %d, \"detect\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"blobs_per_frame\": %.2f", feeds,
+	printf("{\"program\": \"vp_feeds\", \"readback\": \"%s\", \"feeds\": %d, \"steps\": %d, \"host_threads\": %d, \"detect\": %d, \"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"blobs_per_frame\": %.2f", readback == 2 ? "kernel stores into pinned host memory + completion word" : (readback ? "kernel stores into pinned host memory, vp_sync" : "hipMemcpyAsync, vp_sync"), feeds,
 			steps, threads, detect, feeds * (double)steps / dt, 1e3 * dt / steps, blobs / ((double)feeds * steps));
 	if(detect)
 		printf(", \"robots_per_frame\": %.3f, \"balls_per_frame\": %.3f, \"packet_bytes_per_frame\": %.1f, \"rendered\": {\"robots\": %d, \"balls\": %d}", robotsSeen / (double)feeds,
