@@ -7,7 +7,7 @@ import numpy as np, torch
 from _vp_pkg import load
 ap = argparse.ArgumentParser()
 ap.add_argument("stage"); ap.add_argument("batch", type=int)
-ap.add_argument("--cfg", default="cfg2_2048x1536_rggb"); ap.add_argument("--sat", default="tiled"); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--tune", action="append", default=[], help="key=value for vp_ctx_tune")
+ap.add_argument("--cfg", default="cfg2_2048x1536_rggb"); ap.add_argument("--sat", default="tiled"); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--tune", action="append", default=[], help="key=value for vp_ctx_tune"); ap.add_argument("--no-strips", action="store_true", help="sat stage: the pass reads its halo columns from flat instead of the halo strips")
 a = ap.parse_args()
 vp = load(); capi = vp.load_capi()
 cfg = vp.configs.ALL[a.cfg]; B = a.batch; mm = cfg.max_matches
@@ -27,7 +27,7 @@ d_map = torch.zeros((cfg.fh, cfg.fw, 2), dtype=torch.float32, device="cuda")
 ctx.resample_map(cfg.model(), cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, cfg.fw, cfg.fh, d_map)
 strips = None
 nb = ctx.halo_strip_bytes(cfg.fw, cfg.fh, cfg.grad_offset)
-if nb:
+if nb and not a.no_strips:
     strips = torch.zeros((B, nb // 4), dtype=torch.int32, device="cuda")
     ctx.halo_strips(d["flat"], cfg.fw, cfg.fh, cfg.grad_offset, B, strips)
 def fn():

@@ -404,7 +404,13 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	const int hrow0 = hi0 / O, hk0 = hi0 - hrow0 * O, hrow1 = hi1 / O, hk1 = hi1 - hrow1 * O;              \
 	(void)hrow1; (void)hk1
 	auto clamp_row = [&](int Y0, int row) { return (uint32_t)vp_clampi(Y0 - O + row, 0, h - 1); };
+	// VP_SAT_ABLATE (tools/abbuild.sh builds for the traffic attribution of profiles/r06_pmc_hbm.json; WRONG RESULTS BY DESIGN, never defined in the product):
+	// bit 0: the 2 O halo ROWS of a tile are not loaded, bit 1: the halo COLUMNS are not loaded
+#ifndef VP_SAT_ABLATE
+#define VP_SAT_ABLATE 0
+#endif
 	auto tile_load = [&](int P, int X0, int Y0, int c4, int r16) -> v4u {
+		if((VP_SAT_ABLATE & 1) && (min(r16 + 16 * P, ROWS - 1) < O || min(r16 + 16 * P, ROWS - 1) >= TH + O)) return v4u{0, 0, 0, 0};
 		const uint32_t rowoff = clamp_row(Y0, min(r16 + 16 * P, ROWS - 1)) * row_bytes;
 		if(!RAG || X0 + TW <= w) return (v4u)__builtin_amdgcn_raw_buffer_load_b128(rs_flat, rowoff + 16u * (uint32_t)c4, (uint32_t)X0 * 4u, LDC ? 0 : 2); // aux 2 = nt: read once
 		// the last tile column of a width that is not a multiple of 64 (workgroup-uniform): columns past the image take the edge
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	};
 	// left side: pixels X0 - O + k; right side: X0 + 64 + k (clamp-to-edge at the image border, gradientDot.cl:20)
 	auto halo_load = [&](bool right, int row, int k, int X0, int Y0) -> uint32_t {
+		if(VP_SAT_ABLATE & 2) return 0u;
 		const uint32_t gy = clamp_row(Y0, row);
 		const int tjx = X0 >> 6;
 		const bool border = right ? tjx + 1 >= a.tilesX : tjx == 0;
