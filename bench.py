@@ -149,6 +149,40 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_traffic_live(args, kernel_substr, seconds=150):
+    """HBM bytes per launch of the roofline kernel, measured IN THIS RUN: two child passes of this very command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
+    / `--pmc WRITE_SIZE` (counters in their own passes, nothing else traced; the program after `--` is python3 itself), each a short run of the same workload, batch
+    and SAT variant.  FETCH_SIZE is doubled -- on gfx950 it tallies every 128-byte line at 64 B, for every load width (MI355X_MICROARCH.md, HBM section; calibrated per
+    access class in profiles/r06_pmc_hbm.json) -- WRITE_SIZE is exact; both are KB.  Returns (bytes, description) or (None, reason): never raises, the headline does not
+    depend on it.  The parent keeps its buffers while the children run (they fit beside them many times over)."""
+    import glob, shutil, tempfile, csv
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                       "--batch", str(args.batch), "--workload", args.workload, "--sat", args.sat, "--order", args.order, "--sampler", args.sampler, "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline", "--no-extras", "--no-verify"]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+                tot, n = 0.0, 0
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            tot += float(row["Counter_Value"])
+                            n += 1
+                if n == 0:
+                    return None, f"no {counter} rows for {kernel_substr} (rocprofv3 rc {r.returncode}: {(r.stderr or r.stdout)[-200:]!r})"
+                vals[counter] = tot / n
+    except Exception as e:  # a profiler that is missing, refuses or hangs must not take the bench line with it
+        return None, f"live PMC passes failed: {e!r}"
+    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return total, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command inside this run (2 steps each), mean per dispatch of {kernel_substr}: "
+                   f"reads {2.0 * vals['FETCH_SIZE'] * 1024 / 1e6:.1f} MB (FETCH_SIZE x 2, gfx950), writes {vals['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
+
+
 def extra_measurements(capi, torch, np, cfg, params, d_raw, flat, sat, matches, counter, idx, B):
     """Measurements beside the headline (BASELINE.json configs[2] and the figures DESIGN.md quotes), taken AFTER the timed region on the same
     resident frames; none of them is `value`.  Returns a dict for the `extras` key."""
@@ -486,6 +520,9 @@ def main():
     ap.add_argument("--plain-alloc", action="store_true", help="frame buffers from plain hipMalloc (no placement check): the allocation lottery of DESIGN.md section 4")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of two frames of the last timed step with the CPU oracle (rank 0, after the timed region)")
     ap.add_argument("--opencl-probe", action="store_true", help="print the OpenCL platform / device report as JSON and exit (used as a child process)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic live (two short child runs of this command under rocprofv3 --pmc); the figure then comes from "
+                    "profiles/hbm_traffic.json if its kernel hash matches, else null")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) this process IS one of those child runs: no children of its own")
     args = ap.parse_args()
     if args.opencl_probe:
         print(json.dumps(opencl_devices()))
@@ -677,6 +714,13 @@ def main():
             ent = json.load(open(tpath)).get(f"{args.workload}/b{B}/{args.sat}", {})
             if ent.get("kernels_hash") == kernels_hash():
                 traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
+        under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)  # never a profiler inside a profiler
+        if world == 1 and not args.no_pmc and not args.pmc_child and not under_profiler:
+            live, why = pmc_traffic_live(args, {"tiled": "k_sat_fast2", "local": "k_flat_walk"}[args.sat]) if args.sat in ("tiled", "local") else (None, "the two-pass variant is several kernels")
+            if live is not None:
+                traffic, traffic_src = round(live), why
+            else:
+                traffic_src = (traffic_src or "none") + f" [live PMC unavailable: {why}]"
         out = {
             "metric": "frames/s at 2048x1536 (whole hot path raw2quad->blobList, inputs resident in HBM)",
             "value": round(world * B * args.steps / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
