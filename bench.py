@@ -153,7 +153,7 @@ def pmc_traffic_live(args, kernel_substr, seconds=150):
     """HBM bytes per launch of the roofline kernel, measured IN THIS RUN: two child passes of this very command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` (counters in their own passes, nothing else traced; the program after `--` is python3 itself), each a short run of the same workload, batch
     and SAT variant.  FETCH_SIZE is doubled -- on gfx950 it tallies every 128-byte line at 64 B, for every load width (MI355X_MICROARCH.md, HBM section; calibrated per
-    access class in profiles/r06_pmc_hbm.json) -- WRITE_SIZE is exact; both are KB.  Returns (bytes, description) or (None, reason): never raises, the headline does not
+    access class in profiles/r06_pmc_sat_attribution.json) -- WRITE_SIZE is exact; both are KB.  Returns (bytes, description) or (None, reason): never raises, the headline does not
     depend on it.  The parent keeps its buffers while the children run (they fit beside them many times over)."""
     import glob, shutil, tempfile, csv
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"

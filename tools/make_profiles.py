@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "gpurun_out", "prof")
 OUT = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def _csv_under(name, suffix):
@@ -64,13 +64,13 @@ for variant, names in (("local", ("k_flat_walk",)), ("nearest", ("k_resample_sta
     if os.path.isdir(st):
         shutil.copy(_csv_under(f"stats_{variant}", "kernel_stats.csv"), os.path.join(OUT, f"{tag}_kernel_stats_{variant}.csv"))
 old = {}
-for prev in ("r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json"):  # the correction note and the membench calibration are carried along
+for prev in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json"):  # the correction note and the membench calibration are carried along
     if os.path.exists(os.path.join(OUT, prev)):
         old = json.load(open(os.path.join(OUT, prev)))
         break
 frames = bench["config"]["frames_per_step_per_gpu"]
 doc = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2  (tools/profile_round.sh)",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-pmc --no-cpu-baseline --no-extras --steps 5 --warmup 2  (tools/profile_round.sh)",
     "workload": f"{bench['config']['workload']}, {frames} frames per launch",
     "correction": old.get("correction", ""),
     "kernels": kernels,

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, WPC) void k_sat_fast2(const uint32_t* __restri
 	const int hrow0 = hi0 / O, hk0 = hi0 - hrow0 * O, hrow1 = hi1 / O, hk1 = hi1 - hrow1 * O;              \
 	(void)hrow1; (void)hk1
 	auto clamp_row = [&](int Y0, int row) { return (uint32_t)vp_clampi(Y0 - O + row, 0, h - 1); };
-	// VP_SAT_ABLATE (tools/abbuild.sh builds for the traffic attribution of profiles/r06_pmc_hbm.json; WRONG RESULTS BY DESIGN, never defined in the product):
+	// VP_SAT_ABLATE (tools/abbuild.sh builds for the traffic attribution of profiles/r06_pmc_sat_attribution.json; WRONG RESULTS BY DESIGN, never defined in the product):
 	// bit 0: the 2 O halo ROWS of a tile are not loaded, bit 1: the halo COLUMNS are not loaded
 #ifndef VP_SAT_ABLATE
 #define VP_SAT_ABLATE 0
