@@ -56,6 +56,24 @@ def test_abi_version_and_struct_sizes(built):
     assert hip.vp_abi_sizeof(b"VpMatch") == 22 and hip.vp_abi_sizeof(b"VpCameraModel") == 72 and hip.vp_abi_sizeof(b"nope") == 0
 
 
+def test_wait_word_is_a_pure_host_wait(built):
+    """vp_wait_word (the host half of vp_records_compact_signal) touches no device: it returns when the word holds the value, times out with VP_ERR_TIMEOUT otherwise."""
+    import threading
+    import time
+    import numpy as np
+    hip = cases.vp.load_capi().lib()
+    hip.vp_wait_word.argtypes = [C.c_void_p, C.c_uint32, C.c_double]
+    w = np.zeros(16, np.uint32)
+    w[0] = 7
+    assert hip.vp_wait_word(w.ctypes.data, 7, 0.5) == 0
+    t0 = time.perf_counter()
+    assert hip.vp_wait_word(w.ctypes.data, 8, 0.05) == -4          # VP_ERR_TIMEOUT
+    assert 0.04 < time.perf_counter() - t0 < 2.0
+    threading.Timer(0.05, lambda: w.__setitem__(0, 8)).start()      # another thread stores the value while the call spins (ctypes releases the GIL)
+    assert hip.vp_wait_word(w.ctypes.data, 8, 5.0) == 0
+    assert hip.vp_wait_word(None, 1, 0.01) == -1                    # VP_ERR_INVALID
+
+
 def test_multi_gpu_library_exports_the_gather(built):
     """include/vp_multi.h (one process, N devices, RCCL all-gather of the per-step records) lives in libvp_multi.so; libvp_hip.so
     itself stays free of the RCCL dependency.  Without a GPU the constructor fails loudly.  (Loaded in a child process: RCCL brings the
