@@ -15,7 +15,7 @@ cfgs = cases.cfgs
 BIN = os.path.join(cases.ROOT, "vision-processor_amd", "host", "vp_frame_loop")
 
 
-def run_loop(cfg, frames, seed, mode, tmp_path, debug_dump=None):
+def run_loop(cfg, frames, seed, mode, tmp_path, debug_dump=None, debug_images=False):
     dump = str(tmp_path / f"{cfg.name}_{mode}.bin")
     args = [BIN, str(cfg.layout), str(cfg.qw), str(cfg.qh), str(cfg.cam_height), str(cfg.visible_len), str(cfg.distortion), str(cfg.field_len), str(cfg.field_wid),
             str(frames), str(0x5EED0000 + seed), str(cfg.n_robots), str(cfg.n_balls), mode]
@@ -26,7 +26,10 @@ def run_loop(cfg, frames, seed, mode, tmp_path, debug_dump=None):
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     if debug_dump:
         env["VP_DEBUG_DUMP"] = debug_dump
-    out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+    if debug_images:
+        env["VP_DEBUG_IMAGES"] = "1"
+        os.makedirs(tmp_path / "img", exist_ok=True)  # CLImage::save writes "img/" + name + suffix relative to the working directory (opencl.cpp:171)
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout + out.stderr
     recs = []
     with open(dump, "rb") as f:
@@ -159,3 +162,33 @@ def test_native_multi_feed_pipeline():
     assert r["feeds"] == 6 and r["steps"] == 4 and r["detect"] == 1
     assert r["robots_per_frame"] == 16.0 and 8.0 <= r["balls_per_frame"] <= 9.0 and 100 < r["blobs_per_frame"] < 200
     assert 500 < r["packet_bytes_per_frame"] < 1500 and r["frames_per_s"] > 100
+
+
+def test_debug_images_are_saved_as_the_reference_saves_them(port, tmp_path):
+    """main.cpp:291-295 with debug.images on: flat->save(".flat.1.png"), gradDot->save(".gradDot.1.png", 0.25f, 128.f), blobCenter->save(".blob.1.png") --
+    CLImage::save of the facade (opencl.cpp:161-179 without OpenCV: PNGs written by vph_write_png).  Decoded by an independent reader and held to the oracle's
+    images: flat's three colour channels, gradDot and blobCenter through cv::saturate_cast<uint8_t>(factor * v + offset)."""
+    PIL = pytest.importorskip("PIL.Image")
+    cfg, seed = cfgs.T_MID, 70
+    recs, _ = run_loop(cfg, 1, seed, "direct", tmp_path, debug_images=True)
+    assert len(recs) == 1
+    model = O.CameraModel.from_array(np.frombuffer(bytes(cfg.model()), np.uint8))
+    raw = cfg.synth(seed)
+    planes = port.raw2quad(raw, cfg.layout, cfg.qw, cfg.qh)
+    flat = port.resample(planes, cfg.layout, model, cfg.max_robot_height, cfg.field_scale, cfg.off_x, cfg.off_y, 1, cfg.fw, cfg.fh)
+    ch = port.chain_from_flat(flat, cfg.grad_offset, cfg.circle_radius, cfg.list_radius, cfg.circ_threshold, cfg.min_score, cfg.max_matches)
+
+    def grey(v, factor, offset):  # cv::saturate_cast<uint8_t>(float): round half to even, saturate
+        t = np.float32(factor) * v.astype(np.float32) + np.float32(offset)
+        return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+    def load(suffix, mode):
+        im = PIL.open(tmp_path / "img" / suffix)   # RawImage::name is empty for the synthetic camera: "img/" + "" + suffix
+        im.load()
+        assert im.mode == mode and im.size == (cfg.fw, cfg.fh)
+        return np.asarray(im)
+
+    assert np.array_equal(load(".flat.1.png", "RGB"), flat[..., :3])
+    assert np.array_equal(load(".gradDot.1.png", "L"), grey(ch["graddot"], 0.25, 128.0))
+    assert np.array_equal(load(".blob.1.png", "L"), grey(ch["blobcenter"], 1.0, 0.0))
+    assert grey(ch["graddot"], 0.25, 128.0).std() > 1.0  # not a blank image

@@ -68,6 +68,7 @@ int main(int argc, char* argv[]) {
 	}
 	FILE* dump = argc > ai ? fopen(argv[ai], "wb") : nullptr;
 	FILE* debugDump = getenv("VP_DEBUG_DUMP") ? fopen(getenv("VP_DEBUG_DUMP"), "wb") : nullptr; // debugImages (main.cpp:291)
+	r.debugImages = getenv("VP_DEBUG_IMAGES") != nullptr; // debug.images of the reference's config.yml (Resources.cpp:201): img/<name><suffix> PNGs of the first frame
 
 	CLArray matchArray((int)sizeof(CLMatch) * r.maxBlobs); // main.cpp:257-258
 	CLArray counter((int)sizeof(int) * 3);
@@ -101,6 +102,11 @@ int main(int argc, char* argv[]) {
 			}
 			fclose(debugDump);
 			debugDump = nullptr;
+		}
+		if(r.debugImages && frameId == 1) { // main.cpp:291-295 (the reference saves after the blobList launch; the images are complete here already)
+			flat->save(".flat." + std::to_string(frameId) + ".png");
+			gradDot->save(".gradDot." + std::to_string(frameId) + ".png", 0.25f, 128.f);
+			blobCenter->save(".blob." + std::to_string(frameId) + ".png");
 		}
 		{
 			CLMap<int> counterMap = counter.write<int>(); // main.cpp:283-288
