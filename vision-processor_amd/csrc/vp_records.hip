@@ -95,7 +95,7 @@ static int records_compact(VpContext* ctx, int stream, const int32_t* counter, c
 		if(!ctx->compact_arrived[stream]) {
 			VP_REQUIRE(!ctx->capturing[stream], "first vp_records_compact_signal on this stream inside a graph capture");
 			VP_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->compact_arrived[stream]), 256));
-			VP_CHECK_HIP(hipMemset(ctx->compact_arrived[stream], 0, 256));
+			VP_CHECK_HIP(hipMemsetAsync(ctx->compact_arrived[stream], 0, 256, ctx->streams[stream])); // on the launch's own stream: ordered before the kernel that counts on it
 		}
 		arrived = ctx->compact_arrived[stream];
 	}

@@ -3,7 +3,7 @@
 //   tracker, SSL_WrapperPacket (vph_detect_batch_slots on host threads), the CPU stage of step k running while the GPU works on step k + 1.
 // This is the loop of src/main.cpp:262-372 for many cameras at once: what a deployment that puts several cameras on one MI355X runs.
 //
-// usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1]
+// usage: vp_feeds [feeds=128] [steps=20] [warmup=3] [host_threads=16] [detect=1] [readback=2: completion word | 1: host block + vp_sync | 0: device block + copy + vp_sync] [stage_events=0]
 //        vp_feeds --gpus N [feeds per GPU=128] [steps=20] [warmup=3] [--detect] [--threads T=16] [--cap C=192] [--full-records] [--local] [--verify] [--dump FILE]
 //            feeds_multi.cpp: N devices, one driver thread each, one RCCL all-gather per step of the encoded SSL_WrapperPackets (--detect: the CPU stage
 //            runs per device on T / N host threads) or of the compact blob records (--cap records per feed; --full-records: the fixed-capacity arrays
@@ -189,9 +189,10 @@ int main(int argc, char** argv) {
 		const auto l0 = now();
 		const int s = k & 1;
 		CK(vp_frame(ctx, s, &p, dRaw, feeds, &buf[s]));
-		// the compact block is 1.3 MB per 256 feeds: the kernel stores it straight into the pinned host block (hipHostMalloc memory is device-visible), which
-		// becomes readable with the stream's completion; as a separate copy command behind the kernel it added 0.65 ms of waiting per step
-		// (profiles/r06_vp_feeds.jsonl)
+		// the compact block is 1.3 MB per 256 feeds: the kernel stores it straight into the pinned host block (hipHostMalloc memory is device-visible) and its
+		// last workgroup then stores the step number into the set's completion word, which the CPU stage polls instead of synchronising the stream.  Same rate as
+		// device block + copy + vp_sync here (the step is bound by the CPU stage or by the kernels, profiles/r06_vp_feeds.jsonl); kept as the form without a
+		// copy command and without a round trip through the command processor
 		if(readback == 2) CK(vp_records_compact_signal(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, static_cast<uint8_t*>(hSlots[s]), doneWord + 16 * s, (uint32_t)(k + 1)));
 		else if(readback) CK(vp_records_compact(ctx, s, buf[s].counter, buf[s].matches, nullptr, feeds, maxBlobs, cap, static_cast<uint8_t*>(hSlots[s])));
 		else {
@@ -265,6 +266,7 @@ int main(int argc, char** argv) {
 		vp_free_host(ctx, hSlots[s]);
 	}
 	vp_free_device(ctx, dRaw);
+	vp_free_host(ctx, doneWord);
 	vp_ctx_destroy(ctx);
 	return 0;
 }
