@@ -357,9 +357,9 @@ int vp_records_compact(VpContext* ctx, int stream, const int32_t* counter, const
 /* The same with a completion WORD for host loops that read the records back (main.cpp:297-301 maps and waits): `out` and `done_word` live in pinned host memory
  * (vp_malloc_host; device-visible), the kernel stores the slots there itself and its last workgroup then stores `done_value` into *done_word at system scope.
  * The host waits with vp_wait_word (a spin on its own memory: VP_OK, or VP_ERR_TIMEOUT after timeout_s seconds, 0 = wait for ever) instead of vp_sync: the
- * completion reaches it without a marker packet and an interrupt -- on an MI355X whose queues have run dry that round trip costs ~0.6 ms (the device has to be
- * woken to answer; profiles/r06_vp_feeds.jsonl), and ~10 us per step otherwise.  Use a value that changes from step to step (a step counter).  An error raised
- * by the stream's kernels is still reported by vp_sync only. */
+ * completion reaches it without a copy command, a marker packet or an interrupt (no faster than copy + vp_sync where the step is bound by the kernels or by the
+ * host's own stage: profiles/r06_vp_feeds.jsonl; the form for loops that must not block in the runtime).  Use a value that changes from step to step (a step
+ * counter).  An error raised by the stream's kernels is still reported by vp_sync only. */
 int vp_records_compact_signal(VpContext* ctx, int stream, const int32_t* counter, const VpMatch* matches, const uint32_t* idx, int batch, int max_matches, int cap, uint8_t* out,
 		uint32_t* done_word, uint32_t done_value);
 int vp_wait_word(const volatile uint32_t* word, uint32_t value, double timeout_s);
