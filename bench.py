@@ -149,7 +149,7 @@ def kernels_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_live(args, kernel_substr, seconds=150):
+def pmc_traffic_live(args, kernel_substr, seconds=90):
     """HBM bytes per launch of the roofline kernel, measured IN THIS RUN: two child passes of this very command under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
     / `--pmc WRITE_SIZE` (counters in their own passes, nothing else traced; the program after `--` is python3 itself), each a short run of the same workload, batch
     and SAT variant.  FETCH_SIZE is doubled -- on gfx950 it tallies every 128-byte line at 64 B, for every load width (MI355X_MICROARCH.md, HBM section; calibrated per
