@@ -124,6 +124,59 @@ def device_disassembly(so_path, tmp_path):
     return out
 
 
+def device_kernel_metadata(so_path, tmp_path):
+    """{demangled-ish kernel symbol: (vgprs, LDS bytes, scratch bytes)} from the AMDGPU metadata notes of every gfx950 code object in the library."""
+    import yaml
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat = os.path.join(tmp_path, "fat_md.bin")
+    subprocess.run(["objcopy", "--dump-section", f".hip_fatbin={fat}", so_path, os.path.join(tmp_path, "copy_md.so")], check=True)
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    kernels = {}
+    for i, a in enumerate(starts):
+        piece = os.path.join(tmp_path, f"md_bundle{i}.bin")
+        open(piece, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = os.path.join(tmp_path, f"md_dev{i}.co")
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        doc = notes[notes.index("---"):]
+        doc = doc[:doc.index("...")] if "..." in doc else doc
+        for k in yaml.safe_load(doc).get("amdhsa.kernels", []):
+            name = subprocess.run(["c++filt", k[".name"]], capture_output=True, text=True).stdout.strip() or k[".name"]
+            kernels[name] = (k[".vgpr_count"] + k.get(".agpr_count", 0), k[".group_segment_fixed_size"], k[".private_segment_fixed_size"])
+    return kernels
+
+
+def test_hot_kernels_keep_the_occupancy_their_design_depends_on(built, tmp_path):
+    """The register and LDS budgets DESIGN.md section 3 quotes, read back from the built library: the frame-pair resampling kernel at <= 64 VGPRs and 20 KB of LDS (eight
+    wavefronts per SIMD; round 5 found 7 -> 8 worth 3 %), the single-pass SAT at <= 96 VGPRs (five workgroups per CU; its LDS is dynamic), the register walkers at <= 64 / <= 80,
+    the record kernel within one workgroup's share, and nothing on the hot path spilling to scratch.  A compiler or source change that silently costs a wavefront fails here, on the
+    CPU, before anybody measures it on the GPU."""
+    md = device_kernel_metadata(os.path.join(PKG, "libvp_hip.so"), str(tmp_path))
+
+    def pick(prefix):
+        hits = {k: v for k, v in md.items() if k.startswith(prefix)}
+        assert hits, (prefix, sorted(md)[:10])
+        return hits
+
+    for name, (vgpr, lds, scratch) in pick("void k_resample_staged<0, 3,").items():
+        assert vgpr <= 64 and lds <= 20480 and scratch == 0, (name, vgpr, lds, scratch)
+    for name, (vgpr, lds, scratch) in pick("void (anonymous namespace)::k_sat_fast2<2, 5,").items():
+        hot = "<2, 5, false, false," in name  # the benchmark's instantiations; the gradDot-view / ragged-width ones may keep a few bytes of scratch
+        assert vgpr <= 96 and lds == 0 and (scratch == 0 if hot else scratch <= 64), (name, vgpr, lds, scratch)
+    for name, (vgpr, lds, scratch) in pick("void (anonymous namespace)::k_sat_fast2<2, 6,").items():
+        assert vgpr <= 80 and scratch <= 64, (name, vgpr, scratch)  # the optional six-per-CU form buys its wavefront with a few spilled dwords
+    for name, (vgpr, lds, scratch) in pick("void k_circle_walk<5,").items():
+        assert vgpr <= 64 and lds <= 16384 and scratch == 0, (name, vgpr, lds, scratch)
+    for name, (vgpr, lds, scratch) in pick("void k_flat_walk<5, 2>").items():
+        assert vgpr <= 80 and scratch == 0, (name, vgpr)
+    for name, (vgpr, lds, scratch) in pick("k_emit_queue").items():
+        assert vgpr <= 64 and lds <= 65536 and scratch == 0, (name, vgpr, lds, scratch)
+    spills = {k: v[2] for k, v in md.items() if v[2] and any(t in k for t in ("k_resample_staged<0, 3", "k_sat_fast2<2, 5, false, false", "k_circle_walk<5, false", "k_flat_walk<5, 2", "k_emit_queue", "k_records_compact"))}
+    assert not spills, spills
+
+
 def test_no_reversed_dpp_subtraction_in_the_device_code(built, tmp_path):
     """On gfx950 (ROCm 7.2) v_subrev_u32_dpp / v_subrev_f32_dpp shift the wrong operand (a - shl(e) executes as shl(a) - e; shown in
     isolation by tools/dbg/dpp_test.hip, found as wrong blobCenter values in round 2).  hipcc emits the instruction when a DPP-shifted
