@@ -45,6 +45,9 @@ class ProbeImage(C.Structure):
 
 @pytest.fixture(scope="module")
 def probe(tmp_path_factory):
+    if not os.path.exists(REF_SO) and os.path.isdir("/root/reference/kernel"):
+        import oracle as O
+        O.build(ref=True)  # the build container: compile the reference's kernels + the shim now (oracle/Makefile)
     if not os.path.exists(REF_SO):
         pytest.skip("oracle/_ref/libvpref.so not built (needs /root/reference)")
     if not os.path.exists(CLANG):
