@@ -156,3 +156,47 @@ def test_records_reach_the_host_through_a_completion_word(env, port):
         ctx.free_host(h_word)
     finally:
         ctx.close()
+
+
+def test_completion_words_of_two_streams_and_truncated_slots(env, port):
+    """Two library streams signal into two words at once (each stream has its own arrival counter), a single-frame launch signals too (one workgroup is the last
+    one), and a slot too small for a frame's blobs says so (n < min(counter[0], max_matches)) exactly as vp_records_compact does."""
+    import ctypes as C
+    capi, torch = env
+    cfg, mm, cap = cfgs.T_MID, cfgs.T_MID.max_matches, 16
+    ctx = capi.Context(0, n_streams=2)
+    try:
+        capi.lib().vp_record_layout_compact.restype = C.c_size_t
+        slot, offm, offi = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        B = [4, 1]
+        totals = [capi.lib().vp_record_layout_compact(b, cap, C.byref(slot), C.byref(offm), C.byref(offi)) for b in B]
+        h_slots = [ctx.malloc_host(t) for t in totals]
+        h_word = ctx.malloc_host(256)
+        words = (C.c_uint32 * 64).from_address(h_word)
+        for i in range(64): words[i] = 0
+        p = capi.frame_params(cfg, sat_variant=capi.SAT_TILED, order=capi.ORDER_RASTER)
+        bufs = [Buffers(torch, cfg, b, mm) for b in B]
+        raws = [[cfg.synth(9500 + 10 * s + i) for i in range(B[s])] for s in range(2)]
+        d_raw = [torch.from_numpy(np.stack(r)).cuda() for r in raws]
+        torch.cuda.synchronize()
+        for step in (1, 2):
+            for s in range(2):
+                ctx.frame(p, d_raw[s], B[s], stream=s, **bufs[s].kw())
+                ctx.records_compact_signal(bufs[s].cnt, bufs[s].m, bufs[s].idx, B[s], mm, cap, h_slots[s], h_word + 64 * s, 100 * step + s, stream=s)
+            for s in (1, 0):
+                ctx.wait_word(h_word + 64 * s, 100 * step + s, 20.0)
+                host = np.ctypeslib.as_array((C.c_uint8 * totals[s]).from_address(h_slots[s])).copy()
+                for f in range(B[s]):
+                    wm, widx, wcnt = oracle_frame(port, cfg, raws[s][f], mm)
+                    head = host[f * slot.value:f * slot.value + 16].view(np.int32)
+                    assert head[:3].tolist() == wcnt.tolist() and int(wcnt[0]) > cap
+                    assert head[3] == cap                                                  # truncated: the slot holds cap of the counter[0] records
+                    s0 = f * slot.value
+                    assert host[s0 + 16:s0 + 16 + 22 * cap].tobytes() == wm[:cap].tobytes()
+                    assert np.array_equal(host[s0 + offi.value:s0 + offi.value + 4 * cap].view(np.uint32), widx[:cap])
+        ctx.sync()
+        ctx.flush()
+        for hs in h_slots: ctx.free_host(hs)
+        ctx.free_host(h_word)
+    finally:
+        ctx.close()
