@@ -165,7 +165,7 @@ def pmc_traffic_live(args, kernel_substr, seconds=90):
             with tempfile.TemporaryDirectory(dir="/tmp") as d:
                 cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                        "--batch", str(args.batch), "--workload", args.workload, "--sat", args.sat, "--order", args.order, "--sampler", args.sampler, "--steps", "2", "--warmup", "1",
-                       "--no-cpu-baseline", "--no-extras", "--no-verify"]
+                       "--prewarm-ms", "0", "--no-cpu-baseline", "--no-extras", "--no-verify"]
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=seconds, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
                 tot, n = 0.0, 0
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -520,6 +520,7 @@ def main():
     ap.add_argument("--plain-alloc", action="store_true", help="frame buffers from plain hipMalloc (no placement check): the allocation lottery of DESIGN.md section 4")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of two frames of the last timed step with the CPU oracle (rank 0, after the timed region)")
     ap.add_argument("--opencl-probe", action="store_true", help="print the OpenCL platform / device report as JSON and exit (used as a child process)")
+    ap.add_argument("--prewarm-ms", type=float, default=1500.0, help="untimed load before the warm-up steps so that the device's clocks have settled (0 = none)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic live (two short child runs of this command under rocprofv3 --pmc); the figure then comes from "
                     "profiles/hbm_traffic.json if its kernel hash matches, else null")
     ap.add_argument("--pmc-child", action="store_true", help="(internal) this process IS one of those child runs: no children of its own")
@@ -660,6 +661,15 @@ def main():
                 pending[s].wait()
                 pending[s] = None
 
+    # Clock warm-up (untimed, before the W warm-up steps): on some boxes the first ~0.3 s of load run 2-3 % slower in EVERY kernel and then speed up in steps,
+    # whatever the buffers (profiles/r06_clock_warmup.json: per-stage times of one process over its first second; fresh processes with 3 / 100 / 400 warm-up
+    # steps) -- the device's clock governor, not the kernels.  W = 3 steps are 9 ms: without this the timed region of a fresh process sits inside that ramp.
+    # A fixed NUMBER of steps, the same on every rank (a step of the multi-rank path issues a collective): --prewarm-ms at the ~11.7 us per frame of this path.
+    n_pre = min(20000, int(args.prewarm_ms / max(0.08, 0.0117 * B))) if args.prewarm_ms > 0 else 0
+    for i in range(n_pre):
+        step()
+        if (i & 7) == 7:
+            torch.cuda.synchronize()  # keep the queue short: the host runs far ahead of 3 ms steps otherwise
     for _ in range(args.warmup):
         step()
     drain()
@@ -727,7 +737,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (fp32 for coordinates and scores)", "data": "synthetic",
             "config": {"workload": cfg.name, "frames_per_step_per_gpu": B, "sensor": "2048x1536 RGGB8", "flat": f"{cfg.fw}x{cfg.fh}", "grad_offset": cfg.grad_offset,
-                       "circle_radius": cfg.circle_radius, "list_radius": cfg.list_radius, "max_blobs": mm, "sat_variant": args.sat, "list_order": args.order,
+                       "circle_radius": cfg.circle_radius, "list_radius": cfg.list_radius, "max_blobs": mm, "sat_variant": args.sat, "list_order": args.order, "prewarm_ms": args.prewarm_ms,
                        "sampler": "NEAREST" if args.sampler == "nearest" else "BILINEAR_RTZ", "sharding": f"{world} independent feeds, 1 per GPU" + (f", {coll} all-gather of detection records per step" if dist else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": roof_kernel, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(sat_ms, 4)},

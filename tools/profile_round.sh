@@ -17,19 +17,19 @@ for b in 1 8 32 64 128 256 512; do
   timeout -k 10 200 python3 $R/bench.py --batch $b --no-cpu-baseline --no-extras --no-pmc 2>/dev/null | tail -1 > $O/bench_b$b.json
 done
 echo "batch sweep done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --no-pmc --no-cpu-baseline --no-extras > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 $R/bench.py --no-pmc --prewarm-ms 0 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
 echo "kernel stats done"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --no-pmc --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --no-pmc --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --no-pmc --prewarm-ms 0 --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --no-pmc --prewarm-ms 0 --no-cpu-baseline --no-extras --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
 echo "pmc done"
 exit 0
 fi
 # the optional variant without a table (k_flat_walk) and the NEAREST reading of resampling.cl:50 (k_resample_staged<0, 2>): kernel stats + HBM bytes
 for v in "local:--sat local" "nearest:--sampler nearest"; do
   tag=${v%%:*}; flags=${v#*:}
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$tag -o s -- python3 $R/bench.py --no-pmc $flags --no-cpu-baseline --no-extras --no-verify > $O/stats_$tag.log 2>&1
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$tag -o p -- python3 $R/bench.py --no-pmc $flags --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/pmc_fetch_$tag.log 2>&1
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$tag -o p -- python3 $R/bench.py --no-pmc $flags --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/pmc_write_$tag.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$tag -o s -- python3 $R/bench.py --no-pmc --prewarm-ms 0 $flags --no-cpu-baseline --no-extras --no-verify > $O/stats_$tag.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$tag -o p -- python3 $R/bench.py --no-pmc --prewarm-ms 0 $flags --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/pmc_fetch_$tag.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$tag -o p -- python3 $R/bench.py --no-pmc --prewarm-ms 0 $flags --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/pmc_write_$tag.log 2>&1
 done
 echo "variants done"
 # SQ counters, one pass per group (never combined with other trace domains), default path and the table-free variant
@@ -38,8 +38,8 @@ G2="GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS
 G3="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 i=0
 for g in "$G1" "$G2" "$G3"; do
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $O/sq_default/$i -o p -- python3 $R/bench.py --no-pmc --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/sq_default_$i.log 2>&1
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $O/sq_local/$i -o p -- python3 $R/bench.py --no-pmc --sat local --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/sq_local_$i.log 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $O/sq_default/$i -o p -- python3 $R/bench.py --no-pmc --prewarm-ms 0 --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/sq_default_$i.log 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $O/sq_local/$i -o p -- python3 $R/bench.py --no-pmc --prewarm-ms 0 --sat local --no-cpu-baseline --no-extras --no-verify --steps 5 --warmup 2 > $O/sq_local_$i.log 2>&1
   i=$((i+1))
 done
 echo "sq done"
