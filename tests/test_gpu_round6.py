@@ -200,3 +200,35 @@ def test_completion_words_of_two_streams_and_truncated_slots(env, port):
         ctx.free_host(h_word)
     finally:
         ctx.close()
+
+
+def test_the_generic_tiled_kernel_times_out_and_recovers_too(env):
+    """The same recovery path through the unfused entry (vp_sat on a float gradDot image: the generic k_sat_tiled, not the benchmark's k_sat_fast2), on a ragged
+    shape, against 64-bit cumulative sums."""
+    capi, torch = env
+    w, h, B = 200, 150, 2      # 4 x 3 tiles, the last column and row partial
+    rng = np.random.default_rng(66)
+    g = rng.integers(-40000, 40000, (B, h, w)).astype(np.float32)
+    want = np.cumsum(np.cumsum(g.astype(np.int64), axis=1), axis=2).astype(np.int32)
+    d_g = torch.from_numpy(g).cuda()
+    d_sat = torch.zeros((B, h, w), dtype=torch.int32, device="cuda")
+    ctx = capi.Context(0, n_streams=1)
+    try:
+        ctx.tune("sat_spin_limit", 3000)
+        ctx.sat(d_g, w, h, B, capi.SAT_TILED, d_sat)
+        ctx.sync(0)
+        assert np.array_equal(d_sat.cpu().numpy(), want)
+        ctx.tune("sat_debug_drop_tile", 1)          # frame 0, tile row 0, tile column 1: (1, 1) and (2, 1) starve
+        ctx.sat(d_g, w, h, B, capi.SAT_TILED, d_sat)
+        ctx.tune("sat_debug_drop_tile", -1)
+        with pytest.raises(capi.VpError) as e:
+            ctx.sync(0)
+        assert e.value.code == -4
+        got = d_sat.cpu().numpy()
+        assert not np.array_equal(got[0], want[0])  # the poisoned frame's table is wrong ...
+        d_sat.zero_()
+        ctx.sat(d_g, w, h, B, capi.SAT_TILED, d_sat)  # ... and the next launch on the stream resets the carry state
+        ctx.sync(0)
+        assert np.array_equal(d_sat.cpu().numpy(), want)
+    finally:
+        ctx.close()
